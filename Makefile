@@ -1,0 +1,33 @@
+# Builds everything in-tree for gfx950:
+#   visual_slam_amd/liborbamd.so      HIP kernels + C ABI (include/orbamd.h)
+#   build/orb_project<ext>.so         pybind11 module with the reference's name and location
+#   oracle/liborb_oracle.so           CPU restatement (test infrastructure only)
+HIPCC      ?= /opt/rocm/bin/hipcc
+CXX        ?= g++
+PYTHON     ?= python3
+ARCH       ?= gfx950
+CSRC       := visual_slam_amd/csrc
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result
+EXT_SUFFIX := $(shell $(PYTHON)-config --extension-suffix 2>/dev/null || $(PYTHON) -c "import sysconfig;print(sysconfig.get_config_var('EXT_SUFFIX'))")
+PYINC      := $(shell $(PYTHON) -m pybind11 --includes)
+
+LIB    := visual_slam_amd/liborbamd.so
+MODULE := build/orb_project$(EXT_SUFFIX)
+
+all: $(LIB) $(MODULE) oracle
+
+$(LIB): $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip $(CSRC)/orb_internal.h $(CSRC)/orb_pattern.h include/orbamd.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip
+
+$(MODULE): $(CSRC)/orb_module.cpp include/orbamd.h $(LIB)
+	mkdir -p build
+	$(CXX) -O2 -std=c++17 -fPIC -shared -fvisibility=hidden $(PYINC) $(CSRC)/orb_module.cpp -o $@ \
+	    -Lvisual_slam_amd -lorbamd -Wl,-rpath,'$$ORIGIN/../visual_slam_amd'
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -f $(LIB) $(MODULE) oracle/liborb_oracle.so
+
+.PHONY: all oracle clean

@@ -1,0 +1,183 @@
+/*
+ * orbamd.h -- C ABI of liborbamd.so, the MI355X (gfx950) implementation of the reference's
+ * custom ORB front-end: FAST segment-test detection, intensity-moment orientation, steered
+ * BRIEF-256 description and brute-force Hamming top-2 matching.
+ *
+ * The reference has no C ABI; its boundary is the pybind11 module `orb_project`
+ * (reference src/main_interface.cpp:104-110) over three static C++ methods
+ * (reference include/orb.hpp:14-20).  Each entry point below names the reference interface it
+ * stands in for.  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * Conventions
+ *   - Every function returns an int status: 0 = ORBAMD_OK, negative = error (see below).
+ *   - A context owns one HIP stream plus grow-only device work buffers.  One context per host
+ *     thread; calls on one context must not overlap.
+ *   - Functions without a suffix take HOST pointers, copy in, run, copy out and return after the
+ *     stream has drained.  Functions ending in `_dev` take DEVICE pointers, only enqueue work on
+ *     the context's stream and return at once; use orbamd_ctx_sync() before reading results.
+ *   - Images are 8-bit, row-major, tightly packed (row stride = W bytes, frame stride = H*W).
+ *   - Keypoint coordinates are (x = column, y = row).  Keypoints come in the reference's scan
+ *     order: ascending y, then ascending x (reference src/orb.cpp:51-52, :100).
+ *   - Descriptors are 32 bytes; bit (k % 8) of byte (k / 8) is test pair k
+ *     (reference src/orb.cpp:188, :223, :228).
+ *   - This library has no CPU code path: without a usable GPU, orbamd_ctx_create() fails.
+ */
+#ifndef ORBAMD_H
+#define ORBAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBAMD_OK            0
+#define ORBAMD_E_BADARG     (-1)  /* null pointer, non-positive size, train rows >= 2^18, ... */
+#define ORBAMD_E_CAPACITY   (-2)  /* caller's output capacity too small; needed size reported */
+#define ORBAMD_E_DEVICE     (-3)  /* a HIP call failed; text via orbamd_last_error() */
+#define ORBAMD_E_NOMEM      (-4)  /* device or host allocation failed */
+#define ORBAMD_E_STATE      (-5)  /* call sequence wrong (e.g. fetch before extract) */
+
+/* Largest train set a matcher call accepts (train indices are packed into 18 bits; OpenCV's
+ * BFMatcher has the same limit). */
+#define ORBAMD_MAX_TRAIN    (1 << 18)
+
+typedef struct orbamd_ctx orbamd_ctx;
+
+/* Library version as major*10000 + minor*100 + patch. */
+int orbamd_version(void);
+/* Static text for a status code. */
+const char* orbamd_status_string(int status);
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int orbamd_ctx_create(int device, orbamd_ctx** out);
+int orbamd_ctx_destroy(orbamd_ctx* ctx);
+/* Use a caller-owned hipStream_t (passed as void*) for all later work; NULL restores the
+ * context's own stream. */
+int orbamd_ctx_set_stream(orbamd_ctx* ctx, void* hip_stream);
+/* Block until everything enqueued on the context's stream has finished. */
+int orbamd_ctx_sync(orbamd_ctx* ctx);
+/* Text of the last HIP failure seen by this context ("" if none). */
+const char* orbamd_last_error(orbamd_ctx* ctx);
+
+/* Per-kernel timing: when enabled, every kernel launch is bracketed by HIP events on the
+ * context's stream.  orbamd_ctx_timing_read() drains the stream and returns, for kernel kind k
+ * (ORBAMD_K_*), the summed milliseconds and launch count since the last reset. */
+#define ORBAMD_K_BGR2GRAY   0
+#define ORBAMD_K_FAST       1
+#define ORBAMD_K_ROWCOUNT   2
+#define ORBAMD_K_ROWSCAN    3
+#define ORBAMD_K_EMIT       4
+#define ORBAMD_K_DESCRIBE   5
+#define ORBAMD_K_KNN2       6
+#define ORBAMD_K_KNN2_MERGE 7
+#define ORBAMD_K_SYNTH      8
+#define ORBAMD_K_RATIO      9
+#define ORBAMD_K_COUNT      10
+int orbamd_ctx_timing_enable(orbamd_ctx* ctx, int on);
+int orbamd_ctx_timing_reset(orbamd_ctx* ctx);
+int orbamd_ctx_timing_read(orbamd_ctx* ctx, double ms_out[ORBAMD_K_COUNT], long launches_out[ORBAMD_K_COUNT]);
+const char* orbamd_kernel_name(int kind);
+
+/* ---- single frame, host pointers (the drop-in path) -------------------------------------- */
+
+/* cv::cvtColor(frame, gray, COLOR_BGR2GRAY) for 8-bit input (reference
+ * src/main_interface.cpp:83): gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15. */
+int orbamd_bgr2gray(orbamd_ctx* ctx, const uint8_t* bgr, int H, int W, uint8_t* gray_out);
+
+/* ORBDescriptor::detectKeypoints (reference src/orb.cpp:24-108; include/orb.hpp:14).
+ * Writes up to `cap` (x, y) pairs to out_xy and the total found to *n_out; returns
+ * ORBAMD_E_CAPACITY (with *n_out set) when the total exceeds cap. */
+int orbamd_detect(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
+                  int32_t* out_xy, int cap, int* n_out);
+
+/* ORBDescriptor::computeOrientation (reference src/orb.cpp:110-140; include/orb.hpp:17) for n
+ * caller-supplied integer keypoints; angle in degrees in [0, 360] as float. */
+int orbamd_orient(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
+                  const int32_t* xy, int n, float* angle_out);
+
+/* ORBDescriptor::computeDescriptors (reference src/orb.cpp:142-234; include/orb.hpp:20).
+ * Keypoints closer than 16 px to an edge get no descriptor; desc_out receives *nv_out rows of
+ * 32 bytes in keypoint order and valid_idx_out (may be NULL) the keypoint index of each row.
+ * desc_out and valid_idx_out must hold n rows. */
+int orbamd_describe(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
+                    const int32_t* xy, const float* angle, int n,
+                    uint8_t* desc_out, int32_t* valid_idx_out, int* nv_out);
+
+/* extract() of the pybind module (reference src/main_interface.cpp:80-101), in two steps so the
+ * caller can size its arrays exactly: orbamd_extract_* runs detect + orient + describe on the
+ * device and reports the counts; orbamd_fetch copies the results of the LAST extract out:
+ *   kp7_out       float32 [n, 7] = [x, y, 7, angle, 0, 0, -1] (reference :39-55)
+ *   desc_out      uint8   [nv, 32]
+ *   valid_idx_out int32   [nv]  keypoint index of each descriptor row (NULL to skip)
+ * orbamd_extract_bgr takes the [H, W, 3] frame the reference's extract() takes. */
+int orbamd_extract_gray(orbamd_ctx* ctx, const uint8_t* gray, int H, int W, int* n_out, int* nv_out);
+int orbamd_extract_bgr(orbamd_ctx* ctx, const uint8_t* bgr, int H, int W, int* n_out, int* nv_out);
+int orbamd_fetch(orbamd_ctx* ctx, float* kp7_out, uint8_t* desc_out, int32_t* valid_idx_out);
+
+/* cv2.BFMatcher(NORM_HAMMING, crossCheck=False).knnMatch(q, t, 2) (call site: reference
+ * views.py:162; src/main.cpp:75).  For each of nq query rows the two train rows with the
+ * smallest Hamming distance, ties broken towards the lower train index, best first.
+ *   idx_out  int32 [nq, 2]   train index, -1 where the train set has fewer rows than needed
+ *   dist_out int32 [nq, 2]   distance in bits, -1 likewise
+ * nt must be < ORBAMD_MAX_TRAIN. */
+int orbamd_knn2(orbamd_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                int32_t* idx_out, int32_t* dist_out);
+
+/* Lowe ratio filter as reference views.py:163-171 applies it to knnMatch output: query i is kept
+ * iff dist[i][0] < 0.75 * dist[i][1].  Kept rows, in query order:
+ *   good_q[m]  = i              (m1.queryIdx)
+ *   good_t2[m] = idx[i][1]      (m2.trainIdx -- the SECOND neighbour, as the reference stores it)
+ *   good_t1[m] = idx[i][0]      (m1.trainIdx, used for the point pairs)
+ * Returns ORBAMD_E_BADARG if any query has fewer than two neighbours (the reference's tuple
+ * unpacking raises there).  Arrays must hold nq entries. */
+int orbamd_ratio_filter(orbamd_ctx* ctx, const int32_t* idx, const int32_t* dist, int nq,
+                        int32_t* good_q, int32_t* good_t2, int32_t* good_t1, int* m_out);
+
+/* ---- frame batches, device pointers ------------------------------------------------------ */
+
+/* Synthetic gray frames written straight into device memory: frame i of the call is frame
+ * (first_frame + i) of the seeded scene (see visual_slam_amd/synth.py for the definition).
+ * density_thr = round(density * 65536). */
+int orbamd_synth_frames_dev(orbamd_ctx* ctx, uint8_t* d_gray, int frames, int H, int W,
+                            int first_frame, uint32_t seed, int cell, int density_thr);
+
+/* BGR -> gray for `frames` frames of H*W pixels (device pointers). */
+int orbamd_bgr2gray_dev(orbamd_ctx* ctx, const uint8_t* d_bgr, int frames, int H, int W,
+                        uint8_t* d_gray);
+
+/* detect + orient + describe for `frames` gray frames resident in device memory.  Outputs are
+ * frame-strided with a fixed per-frame capacity `cap`:
+ *   d_kp7       float32 [frames, cap, 7]
+ *   d_desc      uint8   [frames, cap, 32]
+ *   d_valid_idx int32   [frames, cap]
+ *   d_counts    int32   [frames, 2] = (n, nv) -- the TRUE totals; when n > cap only the first
+ *                                      cap keypoints (and their descriptors) are stored.
+ * Rows past the counts are left untouched. */
+int orbamd_extract_batch_dev(orbamd_ctx* ctx, const uint8_t* d_gray, int frames, int H, int W,
+                             int cap, float* d_kp7, uint8_t* d_desc, int32_t* d_valid_idx,
+                             int32_t* d_counts);
+
+/* Top-2 matching for frame pairs inside a batch produced by orbamd_extract_batch_dev.
+ * d_pairs is int32 [npairs, 2] = (query frame, train frame); NULL means the consecutive pairs
+ * (p + 1, p) for p in [0, npairs) -- current frame as query, previous as train
+ * (reference views.py:88-90).  Descriptor counts are read from d_counts on the device (clamped
+ * to cap), so no host round trip separates extraction from matching.
+ *   d_idx  int32 [npairs, cap, 2], d_dist int32 [npairs, cap, 2]  as orbamd_knn2
+ *   d_good uint8 [npairs, cap]  1 iff both neighbours exist and dist0 < 0.75 * dist1
+ *                               (reference views.py:168); may be NULL. */
+int orbamd_knn2_batch_dev(orbamd_ctx* ctx, const uint8_t* d_desc, const int32_t* d_counts,
+                          int frames, int cap, const int32_t* d_pairs, int npairs,
+                          int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
+
+/* Top-2 matching of two descriptor sets in device memory (used for the frame pair that spans
+ * two GPUs' frame ranges, after the boundary descriptors have been received). */
+int orbamd_knn2_dev(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                    int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBAMD_H */

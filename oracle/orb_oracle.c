@@ -1,0 +1,316 @@
+/*
+ * orb_oracle.c -- CPU restatement of the reference's custom ORB front-end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing that ships (the HIP library, the pybind
+ * module, the scheduler) may include, link or call this file.  It exists so
+ * that tests, the smoke check and the bench's cpu_baseline leg have something
+ * to compare the GPU path with.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures for
+ * this path, and it cannot be built or run in this environment (it needs
+ * OpenCV, which is absent).  The restatement below follows the reference's
+ * source text line by line; it is pinned only by hand-derived known-answer
+ * tests and by agreement with an independent NumPy restatement.
+ *
+ * Semantics borrowed from OpenCV that the reference relies on and that are
+ * hard-coded here:
+ *   cvRound(float|double)  = round-half-to-even (SSE cvtss2si / lrint)
+ *   cv::KeyPoint defaults  : angle -1, response 0, octave 0, class_id -1
+ *   CV_PI                  = 3.1415926535897932384626433832795
+ *   cv::Point              = two ints (so the table cast at src/orb.cpp:164 is
+ *                            a stride-2 view of the integer table)
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  No
+ * -march flag: the reference is compiled for baseline x86-64, so x*c - y*s is
+ * two rounded products and one rounded difference (no FMA).
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../visual_slam_amd/csrc/orb_pattern.h"
+
+#define ORC_PI 3.1415926535897932384626433832795
+
+static const int8_t orc_pairs[ORBAMD_PATTERN_PAIRS * 4] = ORBAMD_PATTERN_QUADS_INIT;
+
+/* cvRound(float): round half to even, as the SSE path of OpenCV does. */
+static inline int orc_round_f(float v) { return (int)lrintf(v); }
+
+/* ------------------------------------------------------------------------
+ * cv::cvtColor(BGR2GRAY) for 8-bit input (reference src/main_interface.cpp:83).
+ * OpenCV is not vendored and its version is not pinned by the reference
+ * (requirements.txt:5), so this is the published 4.x fixed-point formula:
+ *   gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15
+ * PARITY UNPINNED for this function.
+ * ---------------------------------------------------------------------- */
+void orc_bgr2gray(const uint8_t* bgr, int H, int W, uint8_t* gray)
+{
+    for (long i = 0; i < (long)H * W; ++i) {
+        int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * ORBDescriptor::detectKeypoints  (reference src/orb.cpp:24-108)
+ * Segment test on the radius-3 circle, threshold 20, inclusive compares,
+ * run of 12 counted over k = 0..15 ONCE with no wrap-around, no non-max
+ * suppression, emission in scan order (row outer, column inner).
+ * Writes (x, y) pairs to xy[2*i], xy[2*i+1] for the first `cap` keypoints and
+ * returns the total number found.
+ * ---------------------------------------------------------------------- */
+static const int orc_circle[16][2] = {  /* {dx, dy}, src/orb.cpp:43-48 */
+    {0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0},  {3, 1},   {2, 2},   {1, 3},
+    {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+
+long orc_detect(const uint8_t* gray, int H, int W, int32_t* xy, long cap)
+{
+    const int threshold = 20, radius = 3;
+    long n = 0;
+    for (int i = radius; i < H - radius; ++i) {
+        for (int j = radius; j < W - radius; ++j) {
+            int Ip = gray[(long)i * W + j];
+            int I1 = gray[(long)(i + orc_circle[0][1]) * W + j + orc_circle[0][0]];
+            int I5 = gray[(long)(i + orc_circle[4][1]) * W + j + orc_circle[4][0]];
+            int I9 = gray[(long)(i + orc_circle[8][1]) * W + j + orc_circle[8][0]];
+            int I13 = gray[(long)(i + orc_circle[12][1]) * W + j + orc_circle[12][0]];
+            int valid = 0;
+            /* quick reject on the four compass points, src/orb.cpp:65-68 */
+            if (((I1 <= Ip - threshold) + (I5 <= Ip - threshold) +
+                 (I9 <= Ip - threshold) + (I13 <= Ip - threshold) >= 3) ||
+                ((I1 >= Ip + threshold) + (I5 >= Ip + threshold) +
+                 (I9 >= Ip + threshold) + (I13 >= Ip + threshold) >= 3)) {
+                int brighter = 0, darker = 0;
+                for (int k = 0; k < 16; ++k) {       /* src/orb.cpp:70-96 */
+                    int Ic = gray[(long)(i + orc_circle[k][1]) * W + j + orc_circle[k][0]];
+                    if (Ic >= Ip + threshold) { brighter++; darker = 0; }
+                    else if (Ic <= Ip - threshold) { darker++; brighter = 0; }
+                    else { brighter = 0; darker = 0; }
+                    if (brighter >= 12 || darker >= 12) { valid = 1; break; }
+                }
+            }
+            if (valid) {
+                if (n < cap) { xy[2 * n] = j; xy[2 * n + 1] = i; }
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * ORBDescriptor::computePatchMoments  (reference src/orb.cpp:236-260)
+ * 31x31 square, pixels outside the image skipped, double accumulators.
+ * ---------------------------------------------------------------------- */
+void orc_moments(const uint8_t* gray, int H, int W, float cx, float cy,
+                 double* m00, double* m10, double* m01)
+{
+    const int patch_radius = 15;
+    double a00 = 0, a10 = 0, a01 = 0;
+    for (int v = -patch_radius; v <= patch_radius; ++v) {
+        for (int u = -patch_radius; u <= patch_radius; ++u) {
+            int col = orc_round_f(cx + (float)u);
+            int row = orc_round_f(cy + (float)v);
+            if (row >= 0 && row < H && col >= 0 && col < W) {
+                double intensity = gray[(long)row * W + col];
+                a00 += intensity;
+                a10 += u * intensity;
+                a01 += v * intensity;
+            }
+        }
+    }
+    *m00 = a00; *m10 = a10; *m01 = a01;
+}
+
+/* ------------------------------------------------------------------------
+ * ORBDescriptor::computeOrientation  (reference src/orb.cpp:110-140)
+ * angle is a float: the double product is narrowed on assignment (:129) and
+ * the += 360.0 is a double add narrowed again (:130-132).
+ * ---------------------------------------------------------------------- */
+float orc_angle_from_moments(double m00, double m10, double m01)
+{
+    float angle;
+    if (m00 != 0) {
+        double angle_rad = atan2(m01, m10);
+        angle = (float)(angle_rad * (180.0 / ORC_PI));
+        if (angle < 0) angle = (float)((double)angle + 360.0);
+    } else {
+        angle = 0;
+    }
+    return angle;
+}
+
+void orc_orient(const uint8_t* gray, int H, int W, const int32_t* xy, long n, float* angle)
+{
+    for (long i = 0; i < n; ++i) {
+        double m00, m10, m01;
+        orc_moments(gray, H, W, (float)xy[2 * i], (float)xy[2 * i + 1], &m00, &m10, &m01);
+        angle[i] = orc_angle_from_moments(m00, m10, m01);
+    }
+}
+
+/* Raw integer moments of one keypoint, for tests of the device reduction. */
+void orc_moments_i(const uint8_t* gray, int H, int W, int x, int y, int64_t* out3)
+{
+    double m00, m10, m01;
+    orc_moments(gray, H, W, (float)x, (float)y, &m00, &m10, &m01);
+    out3[0] = (int64_t)m00; out3[1] = (int64_t)m10; out3[2] = (int64_t)m01;
+}
+
+/* ------------------------------------------------------------------------
+ * ORBDescriptor::computeDescriptors  (reference src/orb.cpp:142-234)
+ * Border filter at 16 px (:156), steered sampling with double cos/sin (:172-174),
+ * float narrowing of each rotated coordinate (:195-199), float add with the
+ * centre then cvRound (:202-206), zero for samples outside the image
+ * (:211-217), bit (k % 8) of byte (k / 8) set iff val1 < val2 (:220-228).
+ * desc receives nv rows of 32 bytes; valid_idx[i] is the keypoint index of
+ * descriptor row i.  Returns nv.
+ * ---------------------------------------------------------------------- */
+void orc_describe_one(const uint8_t* gray, int H, int W, float cx, float cy, float angle_deg,
+                      uint8_t* desc32)
+{
+    double angle_rad = angle_deg * (ORC_PI / 180.0);
+    double cos_theta = cos(angle_rad);
+    double sin_theta = sin(angle_rad);
+    for (int byte = 0; byte < 32; ++byte) {
+        int byte_val = 0;
+        for (int bit = 0; bit < 8; ++bit) {
+            int k = byte * 8 + bit;
+            int p1x = orc_pairs[4 * k], p1y = orc_pairs[4 * k + 1];
+            int p2x = orc_pairs[4 * k + 2], p2y = orc_pairs[4 * k + 3];
+            float x1 = (float)(p1x * cos_theta - p1y * sin_theta);
+            float y1 = (float)(p1x * sin_theta + p1y * cos_theta);
+            float x2 = (float)(p2x * cos_theta - p2y * sin_theta);
+            float y2 = (float)(p2x * sin_theta + p2y * cos_theta);
+            int px1 = orc_round_f(cx + x1), py1 = orc_round_f(cy + y1);
+            int px2 = orc_round_f(cx + x2), py2 = orc_round_f(cy + y2);
+            uint8_t v1 = 0, v2 = 0;
+            if (py1 >= 0 && py1 < H && px1 >= 0 && px1 < W) v1 = gray[(long)py1 * W + px1];
+            if (py2 >= 0 && py2 < H && px2 >= 0 && px2 < W) v2 = gray[(long)py2 * W + px2];
+            if (v1 < v2) byte_val |= (1 << bit);
+        }
+        desc32[byte] = (uint8_t)byte_val;
+    }
+}
+
+long orc_describe(const uint8_t* gray, int H, int W, const int32_t* xy, const float* angle,
+                  long n, uint8_t* desc, int32_t* valid_idx)
+{
+    const int PATCH_RADIUS = 16;
+    long nv = 0;
+    for (long i = 0; i < n; ++i) {
+        float cx = (float)xy[2 * i], cy = (float)xy[2 * i + 1];
+        if (cy - PATCH_RADIUS >= 0 && cy + PATCH_RADIUS < H &&
+            cx - PATCH_RADIUS >= 0 && cx + PATCH_RADIUS < W) {
+            orc_describe_one(gray, H, W, cx, cy, angle[i], desc + 32 * nv);
+            if (valid_idx) valid_idx[nv] = (int32_t)i;
+            ++nv;
+        }
+    }
+    return nv;
+}
+
+/* ------------------------------------------------------------------------
+ * extract()  (reference src/main_interface.cpp:80-101) from the gray frame on:
+ * detect, then (if any keypoint) orient and describe; keypoint rows as
+ * keypoints_to_numpy lays them out (:39-55):
+ *   [x, y, size=7, angle, response=0, octave=0, class_id=-1]
+ * With zero keypoints the angle column is never written and stays at the
+ * KeyPoint default, but there are no rows to show it.
+ * Returns n; *nv_out = descriptor rows.  kp7/desc/valid_idx hold at most cap rows.
+ * ---------------------------------------------------------------------- */
+long orc_extract(const uint8_t* gray, int H, int W, float* kp7, long cap, uint8_t* desc,
+                 int32_t* valid_idx, long* nv_out)
+{
+    int32_t* xy = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(cap > 0 ? cap : 1));
+    float* ang = (float*)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1));
+    long n = orc_detect(gray, H, W, xy, cap);
+    long m = n < cap ? n : cap;
+    long nv = 0;
+    if (m > 0) {
+        orc_orient(gray, H, W, xy, m, ang);
+        nv = orc_describe(gray, H, W, xy, ang, m, desc, valid_idx);
+    }
+    for (long i = 0; i < m; ++i) {
+        float* r = kp7 + 7 * i;
+        r[0] = (float)xy[2 * i]; r[1] = (float)xy[2 * i + 1]; r[2] = 7.f; r[3] = ang[i];
+        r[4] = 0.f; r[5] = 0.f; r[6] = -1.f;
+    }
+    *nv_out = nv;
+    free(xy); free(ang);
+    return n;
+}
+
+/* ------------------------------------------------------------------------
+ * cv2.BFMatcher(NORM_HAMMING, crossCheck=False).knnMatch(d1, d2, 2)
+ * (call site: reference views.py:162; matcher built at views.py:65).
+ * OpenCV is un-vendored and unpinned; this restates the published 4.x
+ * algorithm (BFMatcher::knnMatchImpl -> batchDistance with K = 2): integer
+ * Hamming distances, a K-slot list per query initialised to (INT_MAX, -1),
+ * candidates visited in ascending train index and inserted when strictly
+ * smaller than the last slot, shifting entries that are strictly greater.
+ * The result is the two smallest under (distance, trainIdx) order.
+ * Slots never filled keep idx -1 / dist -1 (OpenCV drops them from the list).
+ * PARITY UNPINNED for this function.
+ * ---------------------------------------------------------------------- */
+static inline int orc_hamming32(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+
+void orc_knn2(const uint8_t* q, long nq, const uint8_t* t, long nt, int32_t* idx, int32_t* dist)
+{
+    const int K = 2;
+    for (long i = 0; i < nq; ++i) {
+        int dk[2] = {INT_MAX, INT_MAX};
+        int ik[2] = {-1, -1};
+        for (long j = 0; j < nt; ++j) {
+            int d = orc_hamming32(q + 32 * i, t + 32 * j);
+            if (d < dk[K - 1]) {
+                int k;
+                for (k = K - 2; k >= 0 && dk[k] > d; k--) {
+                    ik[k + 1] = ik[k];
+                    dk[k + 1] = dk[k];
+                }
+                ik[k + 1] = (int)j;
+                dk[k + 1] = d;
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            idx[2 * i + k] = ik[k];
+            dist[2 * i + k] = ik[k] < 0 ? -1 : dk[k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * Lowe ratio filter as the reference's Python applies it (views.py:163-171):
+ * keep query i iff float(d1) < float(d2) * 0.75; record m1.queryIdx,
+ * m2.trainIdx (the SECOND neighbour's index, as the reference does) and
+ * m1.trainIdx.  The reference's tuple unpacking fails when a query has fewer
+ * than two neighbours; here such a query makes the function return -1.
+ * ---------------------------------------------------------------------- */
+long orc_ratio_filter(const int32_t* idx, const int32_t* dist, long nq, int32_t* good_q,
+                      int32_t* good_t2, int32_t* good_t1)
+{
+    long m = 0;
+    for (long i = 0; i < nq; ++i) {
+        if (idx[2 * i] < 0 || idx[2 * i + 1] < 0) return -1;
+        double d1 = (float)dist[2 * i], d2 = (float)dist[2 * i + 1];
+        if (d1 < d2 * 0.75) {
+            good_q[m] = (int32_t)i;
+            good_t2[m] = idx[2 * i + 1];
+            good_t1[m] = idx[2 * i];
+            ++m;
+        }
+    }
+    return m;
+}
+
+/* Pair-major pattern table, for cross-checks from Python. */
+const int8_t* orc_pattern_pairs(void) { return orc_pairs; }

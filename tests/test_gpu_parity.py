@@ -1,0 +1,146 @@
+"""GPU parity: liborbamd.so (through its C ABI) against the CPU restatement, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import make_test_image
+from visual_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_extract_equal(got, exp):
+    kp, desc, vidx = got
+    ekp, edesc, evidx = exp
+    assert kp.shape == ekp.shape, (kp.shape, ekp.shape)
+    assert np.array_equal(bits(kp), bits(ekp)), "keypoint rows differ (bitwise)"
+    assert np.array_equal(vidx, evidx)
+    assert np.array_equal(desc, edesc)
+
+
+IMAGES = [
+    ("structured_240x320", lambda: make_test_image(240, 320, 1)),
+    ("structured_odd_131x157", lambda: make_test_image(131, 157, 2)),     # W % 4 != 0
+    ("structured_wide_64x515", lambda: make_test_image(64, 515, 3)),      # > 4 tiles, ragged
+    ("structured_tall_300x40", lambda: make_test_image(300, 40, 4)),
+    ("tiny_7x7", lambda: make_test_image(7, 7, 5, nrect=3)),
+    ("tiny_6x9", lambda: make_test_image(6, 9, 6, nrect=3)),              # no interior pixel at all
+    ("small_33x33", lambda: make_test_image(33, 33, 7)),                   # exactly one pixel >= 16 from edges
+    ("synth_480p_f0", lambda: synth.synth_frame(480, 640, 0, cell=12)),
+    ("synth_480p_f1", lambda: synth.synth_frame(480, 640, 1, cell=12)),
+    ("flat", lambda: np.full((100, 120), 77, np.uint8)),
+    ("noise", lambda: np.random.default_rng(9).integers(0, 256, (200, 256), dtype=np.uint8)),
+    ("extremes", lambda: (np.random.default_rng(10).integers(0, 2, (150, 200)) * 255).astype(np.uint8)),
+]
+
+
+@pytest.mark.parametrize("name,make", IMAGES, ids=[n for n, _ in IMAGES])
+def test_extract_gray_matches_oracle(gctx, name, make):
+    img = make()
+    exp = oracle.c.extract_gray(img)
+    got = gctx.extract_gray(img)
+    assert_extract_equal(got, exp)
+
+
+@pytest.mark.parametrize("name,make", IMAGES[:5], ids=[n for n, _ in IMAGES[:5]])
+def test_stages_match_oracle(gctx, name, make):
+    img = make()
+    xy = oracle.c.detect(img)
+    assert np.array_equal(gctx.detect(img), xy)
+    ang = oracle.c.orient(img, xy)
+    assert np.array_equal(bits(gctx.orient(img, xy)), bits(ang))
+    desc, vidx = oracle.c.describe(img, xy, ang)
+    gdesc, gvidx = gctx.describe(img, xy, ang)
+    assert np.array_equal(gvidx, vidx)
+    assert np.array_equal(gdesc, desc)
+
+
+def test_detect_capacity_error(gctx):
+    from visual_slam_amd import _lib
+    img = make_test_image(120, 160, 11)
+    n = len(oracle.c.detect(img))
+    assert n > 4
+    with pytest.raises(_lib.OrbAmdError) as e:
+        gctx.detect(img, cap=3)
+    assert e.value.status == _lib.E_CAPACITY
+
+
+def test_orient_describe_arbitrary_points(gctx):
+    """Caller-supplied keypoints in arbitrary order, some outside the image, arbitrary angles."""
+    img = make_test_image(90, 110, 12)
+    rng = np.random.default_rng(13)
+    xy = np.stack([rng.integers(-5, 115, 300), rng.integers(-5, 95, 300)], axis=1).astype(np.int32)
+    ang = oracle.c.orient(img, xy)
+    assert np.array_equal(bits(gctx.orient(img, xy)), bits(ang))
+    ang2 = rng.uniform(0, 360, 300).astype(np.float32)
+    ang2[:8] = [0, 90, 180, 270, 360, 45, 1e-30, 359.99997]
+    desc, vidx = oracle.c.describe(img, xy, ang2)
+    gdesc, gvidx = gctx.describe(img, xy, ang2)
+    assert np.array_equal(gvidx, vidx)
+    assert np.array_equal(gdesc, desc)
+
+
+def test_bgr2gray_and_extract_bgr(gctx):
+    rng = np.random.default_rng(14)
+    gray = make_test_image(96, 130, 15)
+    bgr = np.stack([gray, np.roll(gray, 3, axis=1), 255 - gray], axis=2)
+    bgr = (bgr.astype(np.int32) + rng.integers(-20, 21, bgr.shape)).clip(0, 255).astype(np.uint8)
+    g = gctx.bgr2gray(bgr)
+    assert np.array_equal(g, oracle.c.bgr2gray(bgr))
+    # all 2^24 colours would be too slow to ship around; sample the cube corners + a random sweep
+    sweep = rng.integers(0, 256, (257, 1023, 3), dtype=np.uint8)
+    assert np.array_equal(gctx.bgr2gray(sweep), oracle.c.bgr2gray(sweep))
+    kp, desc, vidx = gctx.extract_bgr(bgr)
+    ekp, edesc, evidx = oracle.c.extract_gray(oracle.c.bgr2gray(bgr))
+    assert_extract_equal((kp, desc, vidx), (ekp, edesc, evidx))
+
+
+KNN_CASES = [(1, 1), (5, 2), (64, 0), (3, 1), (257, 300), (1000, 1537), (2062, 1895), (300, 5000)]
+
+
+@pytest.mark.parametrize("nq,nt", KNN_CASES)
+def test_knn2_matches_oracle(gctx, nq, nt):
+    q = synth.synth_descriptors(nq, 100 + nq, dup_frac=0.05)
+    t = synth.synth_descriptors(nt, 200 + nt, dup_frac=0.05) if nt else np.zeros((0, 32), np.uint8)
+    if nt >= 8:
+        t[nt // 2] = t[1]        # duplicate train rows: lower index must win
+        t[nt - 1] = t[1]
+        q[0] = t[1]              # exact hit with a three-way tie at distance 0
+    idx, dist = gctx.knn2(q, t)
+    eidx, edist = oracle.c.knn2(q, t)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist, edist)
+
+
+def test_knn2_low_entropy_ties(gctx):
+    """Descriptors from a tiny alphabet: almost every distance is tied."""
+    rng = np.random.default_rng(21)
+    q = (rng.integers(0, 2, (700, 32)) * 255).astype(np.uint8)
+    t = (rng.integers(0, 2, (900, 32)) * 255).astype(np.uint8)
+    idx, dist = gctx.knn2(q, t)
+    eidx, edist = oracle.c.knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+
+
+def test_ratio_filter_matches_oracle(gctx):
+    q = synth.synth_descriptors(1500, 31)
+    t = synth.synth_descriptors(1400, 32)
+    t[:700] = q[:700]
+    t[:700:7, 0] ^= 0x0F      # near-duplicates at distance 4
+    idx, dist = oracle.c.knn2(q, t)
+    got = gctx.ratio_filter(idx, dist)
+    exp = oracle.c.ratio_filter(idx, dist)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    assert 0 < len(exp[0]) < 1500
+    # boundary of the inequality: d1 = 3, d2 = 4 -> 3 < 3.0 is false; d1 = 2, d2 = 3 -> 2 < 2.25 true
+    idx2 = np.array([[0, 1], [2, 3]], np.int32)
+    dist2 = np.array([[3, 4], [2, 3]], np.int32)
+    gq, g2, g1 = gctx.ratio_filter(idx2, dist2)
+    assert gq.tolist() == [1] and g2.tolist() == [3] and g1.tolist() == [2]
+    with pytest.raises(ValueError):
+        gctx.ratio_filter(np.array([[0, -1]], np.int32), np.array([[5, -1]], np.int32))

@@ -1,0 +1,702 @@
+// orb_capi.hip -- the extern "C" surface of liborbamd.so (declared in include/orbamd.h): context,
+// grow-only device work buffers, host<->device staging and kernel sequencing.  No computation on
+// image or descriptor data happens on the host in this file.
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/orbamd.h"
+#include "orb_internal.h"
+
+using namespace orbamd;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TimedLaunch {
+    int kind;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct orbamd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // work buffers
+    DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle;
+    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
+    int32_t* h_counts = nullptr;  // pinned, 4 ints
+
+    // state of the last single-frame extract
+    bool have_extract = false;
+    int last_n = 0, last_nv = 0;
+
+    // per-kernel timing
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ORBAMD_K_COUNT] = {0};
+    long launches[ORBAMD_K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(orbamd_ctx* c, hipError_t e, const char* what)
+{
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? ORBAMD_E_NOMEM : ORBAMD_E_DEVICE;
+}
+
+#define HIPCHK(c, expr)                                   \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return fail((c), e_, #expr); \
+    } while (0)
+
+#define CHK(expr)                       \
+    do {                                \
+        int s_ = (expr);                \
+        if (s_ != ORBAMD_OK) return s_; \
+    } while (0)
+
+int ensure(orbamd_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return ORBAMD_OK;
+    if (b.p) {
+        // buffers may still be in use by queued work
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4;  // head room against repeated regrowth
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return ORBAMD_OK;
+}
+
+hipEvent_t get_event(orbamd_ctx* c)
+{
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Brackets one kernel launch with events when timing is on.
+struct Timed {
+    orbamd_ctx* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(orbamd_ctx* c_, int kind_) : c(c_), kind(kind_)
+    {
+        if (c->timing) {
+            a = get_event(c);
+            b = get_event(c);
+            if (a && b) (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (c->timing && a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({kind, a, b});
+        }
+    }
+};
+
+int post_launch(orbamd_ctx* c, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, e, what);
+    return ORBAMD_OK;
+}
+
+int drain_timing(orbamd_ctx* c)
+{
+    if (c->pending.empty()) return ORBAMD_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& t : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            c->ms[t.kind] += ms;
+            c->launches[t.kind] += 1;
+        }
+        c->pool.push_back(t.a);
+        c->pool.push_back(t.b);
+    }
+    c->pending.clear();
+    return ORBAMD_OK;
+}
+
+int enter(orbamd_ctx* c)
+{
+    if (!c) return ORBAMD_E_BADARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return ORBAMD_OK;
+}
+
+int check_image(int H, int W)
+{
+    // H * MW and H * W must stay well inside 32-bit grid and index arithmetic per frame.
+    if (H <= 0 || W <= 0 || H > 32768 || W > 32768) return ORBAMD_E_BADARG;
+    return ORBAMD_OK;
+}
+
+// FAST mask -> row counts -> row offsets + per-frame totals, for `frames` frames at d_gray.
+int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int32_t* d_counts)
+{
+    const size_t MW = mask_words(W);
+    CHK(ensure(c, c->mask, (size_t)frames * H * MW * 4));
+    CHK(ensure(c, c->rowcnt, (size_t)frames * H * sizeof(int2)));
+    CHK(ensure(c, c->rowoff, (size_t)frames * H * sizeof(int2)));
+    FrameSet fs{d_gray, frames, H, W};
+    {
+        Timed t(c, ORBAMD_K_FAST);
+        launch_fast_mask(fs, (uint32_t*)c->mask.p, c->stream);
+    }
+    CHK(post_launch(c, "fast_mask_kernel"));
+    {
+        Timed t(c, ORBAMD_K_ROWCOUNT);
+        launch_rowcount(fs, (const uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
+    }
+    CHK(post_launch(c, "rowcount_kernel"));
+    {
+        Timed t(c, ORBAMD_K_ROWSCAN);
+        launch_rowscan(fs, (const int2*)c->rowcnt.p, (int2*)c->rowoff.p, d_counts, c->stream);
+    }
+    CHK(post_launch(c, "rowscan_kernel"));
+    return ORBAMD_OK;
+}
+
+int run_emit(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int cap)
+{
+    CHK(ensure(c, c->kpxy, (size_t)frames * cap * sizeof(int2)));
+    CHK(ensure(c, c->kpslot, (size_t)frames * cap * sizeof(int32_t)));
+    FrameSet fs{d_gray, frames, H, W};
+    {
+        Timed t(c, ORBAMD_K_EMIT);
+        launch_emit(fs, (const uint32_t*)c->mask.p, (const int2*)c->rowcnt.p, (const int2*)c->rowoff.p, cap,
+                    (int2*)c->kpxy.p, (int32_t*)c->kpslot.p, c->stream);
+    }
+    return post_launch(c, "emit_kernel");
+}
+
+int read_counts(orbamd_ctx* c, const int32_t* d_counts, int nints)
+{
+    HIPCHK(c, hipMemcpyAsync(c->h_counts, d_counts, sizeof(int32_t) * nints, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+int choose_splits(int nq, int nt, int npairs)
+{
+    // Aim for >= ~2048 workgroups in flight; keep every train chunk >= 256 rows.
+    long blocks = (long)((nq + 255) / 256) * npairs;
+    if (blocks <= 0) return 1;
+    long s = (2048 + blocks - 1) / blocks;
+    long smax = nt / 256;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+int run_knn2(orbamd_ctx* c, Knn2Args& a)
+{
+    if (a.splits > 1) {
+        CHK(ensure(c, c->partial, (size_t)a.npairs * a.splits * a.cap * 2 * sizeof(uint32_t)));
+        a.partial = (uint32_t*)c->partial.p;
+    }
+    {
+        Timed t(c, ORBAMD_K_KNN2);
+        launch_knn2(a, c->stream);
+    }
+    CHK(post_launch(c, "knn2_kernel"));
+    if (a.splits > 1) {
+        {
+            Timed t(c, ORBAMD_K_KNN2_MERGE);
+            launch_knn2_merge(a, c->stream);
+        }
+        CHK(post_launch(c, "knn2_merge_kernel"));
+    }
+    return ORBAMD_OK;
+}
+
+// Single-frame extract on a gray frame already in c->gray.
+int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
+{
+    c->have_extract = false;
+    const uint8_t* d_gray = (const uint8_t*)c->gray.p;
+    CHK(ensure(c, c->counts, 16));
+    CHK(run_detect_counts(c, d_gray, 1, H, W, (int32_t*)c->counts.p));
+    CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
+    const int n = c->h_counts[0], nv = c->h_counts[1];
+    if (n > 0) {
+        CHK(run_emit(c, d_gray, 1, H, W, n));
+        CHK(ensure(c, c->kp7, (size_t)n * 7 * sizeof(float)));
+        CHK(ensure(c, c->desc, (size_t)n * 32));
+        CHK(ensure(c, c->vidx, (size_t)n * sizeof(int32_t)));
+        FrameSet fs{d_gray, 1, H, W};
+        {
+            Timed t(c, ORBAMD_K_DESCRIBE);
+            launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
+                                   (const int32_t*)c->counts.p, n, nullptr, (float*)c->kp7.p, nullptr,
+                                   (uint8_t*)c->desc.p, (int32_t*)c->vidx.p, c->stream);
+        }
+        CHK(post_launch(c, "orient_describe_kernel"));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->last_n = n;
+    c->last_nv = nv;
+    c->have_extract = true;
+    if (n_out) *n_out = n;
+    if (nv_out) *nv_out = nv;
+    return ORBAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbamd_version(void) { return 100; }
+
+const char* orbamd_status_string(int status)
+{
+    switch (status) {
+        case ORBAMD_OK: return "ok";
+        case ORBAMD_E_BADARG: return "bad argument";
+        case ORBAMD_E_CAPACITY: return "output capacity too small";
+        case ORBAMD_E_DEVICE: return "HIP call failed";
+        case ORBAMD_E_NOMEM: return "out of memory";
+        case ORBAMD_E_STATE: return "call sequence wrong";
+        default: return "unknown status";
+    }
+}
+
+const char* orbamd_kernel_name(int kind)
+{
+    static const char* names[ORBAMD_K_COUNT] = {"bgr2gray", "fast_mask", "rowcount", "rowscan", "emit",
+                                                "orient_describe", "knn2", "knn2_merge", "synth", "ratio_compact"};
+    return (kind >= 0 && kind < ORBAMD_K_COUNT) ? names[kind] : "?";
+}
+
+int orbamd_ctx_create(int device, orbamd_ctx** out)
+{
+    if (!out) return ORBAMD_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ORBAMD_E_DEVICE;
+    if (device < 0 || device >= ndev) return ORBAMD_E_BADARG;
+    orbamd_ctx* c = new (std::nothrow) orbamd_ctx();
+    if (!c) return ORBAMD_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_counts, 64, hipHostMallocDefault) != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return ORBAMD_E_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_destroy(orbamd_ctx* c)
+{
+    if (!c) return ORBAMD_E_BADARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
+                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->idx, &c->dist, &c->good,
+                      &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_set_stream(orbamd_ctx* c, void* hip_stream)
+{
+    CHK(enter(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(drain_timing(c));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_sync(orbamd_ctx* c)
+{
+    CHK(enter(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+const char* orbamd_last_error(orbamd_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int orbamd_ctx_timing_enable(orbamd_ctx* c, int on)
+{
+    CHK(enter(c));
+    CHK(drain_timing(c));
+    c->timing = on != 0;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_timing_reset(orbamd_ctx* c)
+{
+    CHK(enter(c));
+    CHK(drain_timing(c));
+    for (int k = 0; k < ORBAMD_K_COUNT; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_timing_read(orbamd_ctx* c, double ms_out[ORBAMD_K_COUNT], long launches_out[ORBAMD_K_COUNT])
+{
+    CHK(enter(c));
+    CHK(drain_timing(c));
+    for (int k = 0; k < ORBAMD_K_COUNT; ++k) {
+        if (ms_out) ms_out[k] = c->ms[k];
+        if (launches_out) launches_out[k] = c->launches[k];
+    }
+    return ORBAMD_OK;
+}
+
+// ---- single frame, host pointers ---------------------------------------------------------------
+
+int orbamd_bgr2gray(orbamd_ctx* c, const uint8_t* bgr, int H, int W, uint8_t* gray_out)
+{
+    CHK(enter(c));
+    if (!bgr || !gray_out) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    const size_t npix = (size_t)H * W;
+    CHK(ensure(c, c->bgr, npix * 3));
+    CHK(ensure(c, c->gray, npix));
+    HIPCHK(c, hipMemcpyAsync(c->bgr.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, ORBAMD_K_BGR2GRAY);
+        launch_bgr2gray((const uint8_t*)c->bgr.p, (uint8_t*)c->gray.p, (long)npix, c->stream);
+    }
+    CHK(post_launch(c, "bgr2gray_kernel"));
+    HIPCHK(c, hipMemcpyAsync(gray_out, c->gray.p, npix, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+int orbamd_detect(orbamd_ctx* c, const uint8_t* gray, int H, int W, int32_t* out_xy, int cap, int* n_out)
+{
+    CHK(enter(c));
+    if (!gray || !n_out || cap < 0 || (cap > 0 && !out_xy)) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    c->have_extract = false;
+    const size_t npix = (size_t)H * W;
+    CHK(ensure(c, c->gray, npix));
+    CHK(ensure(c, c->counts, 16));
+    HIPCHK(c, hipMemcpyAsync(c->gray.p, gray, npix, hipMemcpyHostToDevice, c->stream));
+    CHK(run_detect_counts(c, (const uint8_t*)c->gray.p, 1, H, W, (int32_t*)c->counts.p));
+    CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
+    const int n = c->h_counts[0];
+    *n_out = n;
+    const int m = n < cap ? n : cap;
+    if (m > 0) {
+        CHK(run_emit(c, (const uint8_t*)c->gray.p, 1, H, W, m));
+        HIPCHK(c, hipMemcpyAsync(out_xy, c->kpxy.p, (size_t)m * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return n > cap ? ORBAMD_E_CAPACITY : ORBAMD_OK;
+}
+
+static int upload_keypoints(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int32_t* xy, int n)
+{
+    const size_t npix = (size_t)H * W;
+    CHK(ensure(c, c->gray, npix));
+    CHK(ensure(c, c->kpxy, (size_t)n * sizeof(int2)));
+    CHK(ensure(c, c->kpslot, (size_t)n * sizeof(int32_t)));
+    CHK(ensure(c, c->counts, 16));
+    HIPCHK(c, hipMemcpyAsync(c->gray.p, gray, npix, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->kpxy.p, xy, (size_t)n * sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    return ORBAMD_OK;
+}
+
+int orbamd_orient(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int32_t* xy, int n, float* angle_out)
+{
+    CHK(enter(c));
+    if (!gray || n < 0 || (n > 0 && (!xy || !angle_out))) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    if (n == 0) return ORBAMD_OK;
+    c->have_extract = false;
+    CHK(upload_keypoints(c, gray, H, W, xy, n));
+    CHK(ensure(c, c->angle, (size_t)n * sizeof(float)));
+    c->h_counts[0] = n;
+    c->h_counts[1] = 0;
+    HIPCHK(c, hipMemcpyAsync(c->counts.p, c->h_counts, 8, hipMemcpyHostToDevice, c->stream));
+    FrameSet fs{(const uint8_t*)c->gray.p, 1, H, W};
+    {
+        Timed t(c, ORBAMD_K_DESCRIBE);
+        launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
+                               (const int32_t*)c->counts.p, n, nullptr, nullptr, (float*)c->angle.p, nullptr,
+                               nullptr, c->stream);
+    }
+    CHK(post_launch(c, "orient_describe_kernel"));
+    HIPCHK(c, hipMemcpyAsync(angle_out, c->angle.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+int orbamd_describe(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int32_t* xy, const float* angle,
+                    int n, uint8_t* desc_out, int32_t* valid_idx_out, int* nv_out)
+{
+    CHK(enter(c));
+    if (!gray || !nv_out || n < 0 || (n > 0 && (!xy || !angle || !desc_out))) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    *nv_out = 0;
+    if (n == 0) return ORBAMD_OK;
+    c->have_extract = false;
+    CHK(upload_keypoints(c, gray, H, W, xy, n));
+    CHK(ensure(c, c->angle, (size_t)n * sizeof(float)));
+    CHK(ensure(c, c->desc, (size_t)n * 32));
+    CHK(ensure(c, c->vidx, (size_t)n * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpyAsync(c->angle.p, angle, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    launch_slots((const int2*)c->kpxy.p, n, H, W, (int32_t*)c->kpslot.p, (int32_t*)c->counts.p, c->stream);
+    CHK(post_launch(c, "slots_kernel"));
+    FrameSet fs{(const uint8_t*)c->gray.p, 1, H, W};
+    {
+        Timed t(c, ORBAMD_K_DESCRIBE);
+        launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
+                               (const int32_t*)c->counts.p, n, (const float*)c->angle.p, nullptr, nullptr,
+                               (uint8_t*)c->desc.p, (int32_t*)c->vidx.p, c->stream);
+    }
+    CHK(post_launch(c, "orient_describe_kernel"));
+    CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
+    const int nv = c->h_counts[1];
+    *nv_out = nv;
+    if (nv > 0) {
+        HIPCHK(c, hipMemcpyAsync(desc_out, c->desc.p, (size_t)nv * 32, hipMemcpyDeviceToHost, c->stream));
+        if (valid_idx_out)
+            HIPCHK(c, hipMemcpyAsync(valid_idx_out, c->vidx.p, (size_t)nv * sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return ORBAMD_OK;
+}
+
+int orbamd_extract_gray(orbamd_ctx* c, const uint8_t* gray, int H, int W, int* n_out, int* nv_out)
+{
+    CHK(enter(c));
+    if (!gray) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    const size_t npix = (size_t)H * W;
+    CHK(ensure(c, c->gray, npix));
+    HIPCHK(c, hipMemcpyAsync(c->gray.p, gray, npix, hipMemcpyHostToDevice, c->stream));
+    return extract_resident(c, H, W, n_out, nv_out);
+}
+
+int orbamd_extract_bgr(orbamd_ctx* c, const uint8_t* bgr, int H, int W, int* n_out, int* nv_out)
+{
+    CHK(enter(c));
+    if (!bgr) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    const size_t npix = (size_t)H * W;
+    CHK(ensure(c, c->bgr, npix * 3));
+    CHK(ensure(c, c->gray, npix));
+    HIPCHK(c, hipMemcpyAsync(c->bgr.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, ORBAMD_K_BGR2GRAY);
+        launch_bgr2gray((const uint8_t*)c->bgr.p, (uint8_t*)c->gray.p, (long)npix, c->stream);
+    }
+    CHK(post_launch(c, "bgr2gray_kernel"));
+    return extract_resident(c, H, W, n_out, nv_out);
+}
+
+int orbamd_fetch(orbamd_ctx* c, float* kp7_out, uint8_t* desc_out, int32_t* valid_idx_out)
+{
+    CHK(enter(c));
+    if (!c->have_extract) return ORBAMD_E_STATE;
+    const int n = c->last_n, nv = c->last_nv;
+    if (n > 0 && kp7_out)
+        HIPCHK(c, hipMemcpyAsync(kp7_out, c->kp7.p, (size_t)n * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (nv > 0 && desc_out)
+        HIPCHK(c, hipMemcpyAsync(desc_out, c->desc.p, (size_t)nv * 32, hipMemcpyDeviceToHost, c->stream));
+    if (nv > 0 && valid_idx_out)
+        HIPCHK(c, hipMemcpyAsync(valid_idx_out, c->vidx.p, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx_out,
+                int32_t* dist_out)
+{
+    CHK(enter(c));
+    if (nq < 0 || nt < 0 || nt >= ORBAMD_MAX_TRAIN) return ORBAMD_E_BADARG;
+    if (nq == 0) return ORBAMD_OK;
+    if (!q || !idx_out || !dist_out || (nt > 0 && !t)) return ORBAMD_E_BADARG;
+    CHK(ensure(c, c->q, (size_t)nq * 32));
+    CHK(ensure(c, c->t, (size_t)nt * 32));
+    CHK(ensure(c, c->idx, (size_t)nq * 2 * sizeof(int32_t)));
+    CHK(ensure(c, c->dist, (size_t)nq * 2 * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpyAsync(c->q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    Knn2Args a{};
+    a.qdesc = (const uint8_t*)c->q.p;
+    a.tdesc = (const uint8_t*)c->t.p;
+    a.npairs = 1;
+    a.cap = nq;
+    a.nq_fixed = nq;
+    a.nt_fixed = nt;
+    a.splits = choose_splits(nq, nt, 1);
+    a.idx = (int32_t*)c->idx.p;
+    a.dist = (int32_t*)c->dist.p;
+    CHK(run_knn2(c, a));
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->idx.p, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist_out, c->dist.p, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
+int orbamd_ratio_filter(orbamd_ctx* c, const int32_t* idx, const int32_t* dist, int nq, int32_t* good_q,
+                        int32_t* good_t2, int32_t* good_t1, int* m_out)
+{
+    CHK(enter(c));
+    if (nq < 0 || !m_out) return ORBAMD_E_BADARG;
+    *m_out = 0;
+    if (nq == 0) return ORBAMD_OK;
+    if (!idx || !dist || !good_q || !good_t2 || !good_t1) return ORBAMD_E_BADARG;
+    const size_t b2 = (size_t)nq * 2 * sizeof(int32_t), b1 = (size_t)nq * sizeof(int32_t);
+    CHK(ensure(c, c->idx, b2));
+    CHK(ensure(c, c->dist, b2));
+    CHK(ensure(c, c->rq, b1));
+    CHK(ensure(c, c->rt2, b1));
+    CHK(ensure(c, c->rt1, b1));
+    CHK(ensure(c, c->rcount, 16));
+    HIPCHK(c, hipMemcpyAsync(c->idx.p, idx, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dist.p, dist, b2, hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, ORBAMD_K_RATIO);
+        launch_ratio_compact((const int32_t*)c->idx.p, (const int32_t*)c->dist.p, nq, (int32_t*)c->rq.p,
+                             (int32_t*)c->rt2.p, (int32_t*)c->rt1.p, (int32_t*)c->rcount.p, c->stream);
+    }
+    CHK(post_launch(c, "ratio_compact_kernel"));
+    CHK(read_counts(c, (const int32_t*)c->rcount.p, 1));
+    const int m = c->h_counts[0];
+    if (m < 0) return ORBAMD_E_BADARG;
+    *m_out = m;
+    if (m > 0) {
+        HIPCHK(c, hipMemcpyAsync(good_q, c->rq.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(good_t2, c->rt2.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(good_t1, c->rt1.p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return ORBAMD_OK;
+}
+
+// ---- frame batches, device pointers ------------------------------------------------------------
+
+int orbamd_synth_frames_dev(orbamd_ctx* c, uint8_t* d_gray, int frames, int H, int W, int first_frame,
+                            uint32_t seed, int cell, int density_thr)
+{
+    CHK(enter(c));
+    if (!d_gray || frames <= 0 || cell < 10 || density_thr < 0 || first_frame < 0) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    {
+        Timed t(c, ORBAMD_K_SYNTH);
+        launch_synth(d_gray, frames, H, W, first_frame, seed, cell, density_thr, c->stream);
+    }
+    return post_launch(c, "synth_kernel");
+}
+
+int orbamd_bgr2gray_dev(orbamd_ctx* c, const uint8_t* d_bgr, int frames, int H, int W, uint8_t* d_gray)
+{
+    CHK(enter(c));
+    if (!d_bgr || !d_gray || frames <= 0) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    {
+        Timed t(c, ORBAMD_K_BGR2GRAY);
+        launch_bgr2gray(d_bgr, d_gray, (long)frames * H * W, c->stream);
+    }
+    return post_launch(c, "bgr2gray_kernel");
+}
+
+int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int cap,
+                             float* d_kp7, uint8_t* d_desc, int32_t* d_valid_idx, int32_t* d_counts)
+{
+    CHK(enter(c));
+    if (!d_gray || !d_kp7 || !d_desc || !d_counts || frames <= 0 || frames > 65535 || cap <= 0)
+        return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    c->have_extract = false;
+    CHK(run_detect_counts(c, d_gray, frames, H, W, d_counts));
+    CHK(run_emit(c, d_gray, frames, H, W, cap));
+    FrameSet fs{d_gray, frames, H, W};
+    {
+        Timed t(c, ORBAMD_K_DESCRIBE);
+        launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
+                               d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
+    }
+    return post_launch(c, "orient_describe_kernel");
+}
+
+int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int frames, int cap,
+                          const int32_t* d_pairs, int npairs, int32_t* d_idx, int32_t* d_dist, uint8_t* d_good)
+{
+    CHK(enter(c));
+    if (!d_desc || !d_counts || !d_idx || !d_dist || frames <= 0 || cap <= 0 || cap > ORBAMD_MAX_TRAIN ||
+        npairs < 0 || npairs > 65535)
+        return ORBAMD_E_BADARG;
+    if (!d_pairs && npairs > frames - 1) return ORBAMD_E_BADARG;
+    if (npairs == 0) return ORBAMD_OK;
+    Knn2Args a{};
+    a.qdesc = d_desc;
+    a.tdesc = d_desc;
+    a.counts = d_counts;
+    a.pairs = d_pairs;
+    a.npairs = npairs;
+    a.cap = cap;
+    a.splits = choose_splits(cap, cap, npairs);
+    a.idx = d_idx;
+    a.dist = d_dist;
+    a.good = d_good;
+    return run_knn2(c, a);
+}
+
+int orbamd_knn2_dev(orbamd_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx,
+                    int32_t* d_dist, uint8_t* d_good)
+{
+    CHK(enter(c));
+    if (nq < 0 || nt < 0 || nt >= ORBAMD_MAX_TRAIN) return ORBAMD_E_BADARG;
+    if (nq == 0) return ORBAMD_OK;
+    if (!d_q || !d_idx || !d_dist || (nt > 0 && !d_t)) return ORBAMD_E_BADARG;
+    Knn2Args a{};
+    a.qdesc = d_q;
+    a.tdesc = d_t ? d_t : d_q;
+    a.npairs = 1;
+    a.cap = nq;
+    a.nq_fixed = nq;
+    a.nt_fixed = nt;
+    a.splits = choose_splits(nq, nt, 1);
+    a.idx = d_idx;
+    a.dist = d_dist;
+    a.good = d_good;
+    return run_knn2(c, a);
+}
+
+}  // extern "C"

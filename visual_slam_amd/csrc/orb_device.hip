@@ -1,0 +1,748 @@
+// orb_device.hip -- gfx950 kernels of liborbamd.so and their launchers.
+//
+// Kernels (one wavefront = 64 lanes throughout):
+//   bgr2gray_kernel         byte stream, 4 pixels per lane
+//   synth_kernel            seeded synthetic frames, 4 pixels per lane
+//   fast_mask_kernel        FAST segment test on LDS-staged tiles -> 1 bit per pixel
+//   rowcount_kernel         per image row: number of corners / of corners that get a descriptor
+//   rowscan_kernel          per frame: exclusive prefix over the row counts
+//   emit_kernel             ordered expansion of the bit mask into (x, y) lists (ballot-free
+//                           popcount + wave prefix; ascending y then x by construction)
+//   slots_kernel            descriptor row numbers for caller-supplied keypoint lists
+//   orient_describe_kernel  one wavefront per keypoint: 31x31 moments, atan2, steered BRIEF-256
+//   knn2_kernel             Hamming top-2, one query per lane, train rows broadcast
+//   knn2_merge_kernel       merges train-axis partial results
+//
+// Floating point on the parity path is compiled without contraction: the reference computes
+// x*c - y*s as two rounded products and one rounded difference (reference src/orb.cpp:195-199).
+#include "orb_internal.h"
+#include "orb_pattern.h"
+
+#pragma clang fp contract(off)
+
+namespace orbamd {
+
+// Pair-major sampling pattern in constant memory: bytes 4k .. 4k+3 = {x1, y1, x2, y2} of pair k.
+__constant__ __attribute__((aligned(16))) int8_t c_pairs[ORBAMD_PATTERN_PAIRS * 4] = ORBAMD_PATTERN_QUADS_INIT;
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Bits b of mask word w whose pixel x = 32w + b satisfies x - 16 >= 0 && x + 16 < W.
+__device__ __forceinline__ uint32_t desc_column_bits(int w, int W)
+{
+    int lo = 16 - 32 * w, hi = (W - 17) - 32 * w;
+    if (hi < 0 || lo > 31) return 0u;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 31 ? 31 : hi;
+    uint32_t upto_hi = hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u);
+    return upto_hi & ~((1u << lo) - 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BGR -> gray, OpenCV 4.x 8-bit fixed point (reference src/main_interface.cpp:83).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (b * 3735u + g * 19235u + r * 9798u + (1u << 14)) >> 15;
+}
+
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t* __restrict__ bgr,
+                                                       uint8_t* __restrict__ gray, long npix,
+                                                       int aligned)
+{
+    long quad = (long)blockIdx.x * 256 + threadIdx.x;  // 4 pixels = 12 input bytes
+    long nquad = npix >> 2;
+    long stride = (long)gridDim.x * 256;
+    for (; quad < nquad; quad += stride) {
+        uint32_t w0, w1, w2;
+        if (aligned) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(bgr) + quad * 3;
+            w0 = p[0]; w1 = p[1]; w2 = p[2];
+        } else {
+            const uint8_t* p = bgr + quad * 12;
+            w0 = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+            w1 = p[4] | (p[5] << 8) | (p[6] << 16) | ((uint32_t)p[7] << 24);
+            w2 = p[8] | (p[9] << 8) | (p[10] << 16) | ((uint32_t)p[11] << 24);
+        }
+        uint32_t g0 = gray_of(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255);
+        uint32_t g1 = gray_of(w0 >> 24, w1 & 255, (w1 >> 8) & 255);
+        uint32_t g2 = gray_of((w1 >> 16) & 255, w1 >> 24, w2 & 255);
+        uint32_t g3 = gray_of((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24);
+        uint32_t out = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+        if (aligned) reinterpret_cast<uint32_t*>(gray)[quad] = out;
+        else { uint8_t* o = gray + quad * 4; o[0] = g0; o[1] = g1; o[2] = g2; o[3] = g3; }
+    }
+    // tail pixels (npix not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {
+        long i = (npix & ~3L) + threadIdx.x;
+        gray[i] = (uint8_t)gray_of(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2]);
+    }
+}
+
+void launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long npix, hipStream_t s)
+{
+    long nquad = npix >> 2;
+    long blocks = (nquad + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    int aligned = (((uintptr_t)bgr | (uintptr_t)gray) & 3) == 0;
+    hipLaunchKernelGGL(bgr2gray_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bgr, gray, npix, aligned);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic frames (definition: visual_slam_amd/synth.py).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t hash3(uint32_t seed, uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t h = mix32(seed + 0x9E3779B9u * a);
+    h = mix32(h ^ (0x85EBCA6Bu * b));
+    h = mix32(h + 0xC2B2AE35u * c);
+    return h;
+}
+__device__ __forceinline__ uint32_t synth_pixel(uint32_t x, uint32_t y, uint32_t f, uint32_t seed,
+                                                uint32_t cell, uint32_t thr)
+{
+    uint32_t wx = x + f, wy = y;
+    uint32_t cx = wx / cell, lx = wx % cell, cy = wy / cell, ly = wy % cell;
+    uint32_t phase = hash3(seed ^ 0x5EEDu, cx, cy, 7u) % 20u;
+    uint32_t epoch = (f + phase) / 20u;
+    uint32_t hc = hash3(seed ^ 0xB10Bu, cx, cy, epoch);
+    bool has = (hc & 0xFFFFu) < thr;
+    uint32_t span = cell - 9u;
+    uint32_t bx = 4u + ((hc >> 16) & 0xFFu) % span;
+    uint32_t by = 4u + ((hc >> 24) & 0xFFu) % span;
+    uint32_t h2 = mix32(hc ^ 0xA5A5A5A5u);
+    uint32_t size = 1u + (h2 & 1u);
+    bool bright = ((h2 >> 1) & 1u) != 0;
+    bool inblob = has && lx >= bx && lx < bx + size && ly >= by && ly < by + size;
+    uint32_t bg = 96u + hash3(seed ^ 0xBAC6u, wx, wy, 0u) % 9u;
+    uint32_t hf = hash3(seed ^ 0xF11Cu, x, y, f);
+    if ((hf & 15u) == 0u) bg = bg < 104u ? bg + 1u : bg - 1u;
+    return inblob ? (bright ? 230u : 10u) : bg;
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ gray, int frames, int H,
+                                                    int W, int first_frame, uint32_t seed,
+                                                    uint32_t cell, uint32_t thr)
+{
+    const long per_frame = (long)H * W;
+    const long total = per_frame * frames;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    const bool al = ((uintptr_t)gray & 3) == 0;
+    for (; i < total; i += stride) {
+        uint32_t out = 0;
+        int nb = total - i < 4 ? (int)(total - i) : 4;
+        for (int b = 0; b < nb; ++b) {
+            long j = i + b;
+            uint32_t f = (uint32_t)(j / per_frame);
+            long r = j - (long)f * per_frame;
+            uint32_t y = (uint32_t)(r / W), x = (uint32_t)(r - (long)y * W);
+            out |= synth_pixel(x, y, f + (uint32_t)first_frame, seed, cell, thr) << (8 * b);
+        }
+        if (al && nb == 4) *reinterpret_cast<uint32_t*>(gray + i) = out;
+        else for (int b = 0; b < nb; ++b) gray[i + b] = (uint8_t)(out >> (8 * b));
+    }
+}
+
+void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint32_t seed, int cell,
+                  int density_thr, hipStream_t s)
+{
+    long total = (long)frames * H * W;
+    long blocks = (total / 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gray, frames, H, W,
+                       first_frame, seed, (uint32_t)cell, (uint32_t)density_thr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST segment test (reference src/orb.cpp:24-108).
+//
+// A pixel with its radius-3 circle inside the image is a corner iff 12 consecutive circle pixels
+// k = s .. s+11, s in 0..4 (the reference's run counter never wraps past k = 15), are all
+// >= centre + 20 or all <= centre - 20.  The reference's four-point pre-test (:65-68) is implied
+// by that condition, so it is used here only as a cheap early-out.
+//
+// Tile: 128 x 16 outputs per 256-thread workgroup, staged in LDS with a 3-row / 4-column halo
+// (columns padded to 4 so global reads are whole aligned dwords).  One lane tests one pixel; the
+// wave's ballot is 64 consecutive mask bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int FT_W = 128, FT_H = 16;
+constexpr int FT_LW = FT_W + 8;   // LDS row bytes (136 = 34 dwords)
+constexpr int FT_LH = FT_H + 6;   // LDS rows
+
+// Circle offsets in LDS bytes, k = 0 at (0,-3), clockwise (reference src/orb.cpp:43-48).
+__device__ __forceinline__ constexpr int circ_off(int k)
+{
+    constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int dy[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    return dy[k] * FT_LW + dx[k];
+}
+
+__device__ __forceinline__ bool run12(uint32_t m)
+{
+    // m: 16 class bits; true iff bits s..s+11 are all set for some s in 0..4 (no wrap).
+    m &= m >> 1;
+    m &= m >> 2;
+    m &= m >> 4;   // bit i = bits i..i+7 set
+    m &= m >> 4;   // bit i = bits i..i+11 set
+    return (m & 0x1Fu) != 0;
+}
+
+__global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
+                                                        int W, uint32_t* __restrict__ mask, int MW,
+                                                        int aligned4)
+{
+    __shared__ uint32_t tile32[FT_LH * (FT_LW / 4)];
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+    const int f = blockIdx.z;
+    const uint8_t* img = gray + (size_t)f * H * W;
+    uint32_t* mfr = mask + (size_t)f * H * MW;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+
+    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
+        int r = i / (FT_LW / 4), j = i - r * (FT_LW / 4);
+        int y = y0 - 3 + r, x = x0 - 4 + 4 * j;
+        uint32_t v = 0;
+        if (y >= 0 && y < H) {
+            const uint8_t* row = img + (size_t)y * W;
+            if (aligned4 && x >= 0 && x + 3 < W) {
+                v = *reinterpret_cast<const uint32_t*>(row + x);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int xx = x + b;
+                    if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
+                }
+            }
+        }
+        tile32[i] = v;
+    }
+    __syncthreads();
+
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int ly = wave * 4 + (it >> 1);
+        const int half = it & 1;
+        const int lx = half * 64 + lane;
+        const int x = x0 + lx, y = y0 + ly;
+        const uint8_t* c = tile + (ly + 3) * FT_LW + lx + 4;
+        const int p = c[0];
+        const int hi = p + 20, lo = p - 20;
+        const int n = c[circ_off(0)], e = c[circ_off(4)], s = c[circ_off(8)], w = c[circ_off(12)];
+        const int nb = (n >= hi) + (e >= hi) + (s >= hi) + (w >= hi);
+        const int nd = (n <= lo) + (e <= lo) + (s <= lo) + (w <= lo);
+        const bool inside = x >= 3 && x < W - 3 && y >= 3 && y < H - 3;
+        bool corner = false;
+        if (inside && (nb >= 3 || nd >= 3)) {
+            uint32_t mb = 0, md = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int v = c[circ_off(k)];
+                mb |= (uint32_t)(v >= hi) << k;
+                md |= (uint32_t)(v <= lo) << k;
+            }
+            corner = run12(mb) || run12(md);
+        }
+        const unsigned long long bal = __ballot(corner);
+        if (lane == 0 && y < H) {
+            const int wi = (x0 + half * 64) >> 5;
+            uint32_t* mrow = mfr + (size_t)y * MW;
+            if (wi < MW) mrow[wi] = (uint32_t)bal;
+            if (wi + 1 < MW) mrow[wi + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+}
+
+void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
+{
+    const int MW = mask_words(fs.W);
+    dim3 grid((fs.W + FT_W - 1) / FT_W, (fs.H + FT_H - 1) / FT_H, fs.frames);
+    int aligned4 = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
+    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ordered compaction of the corner mask.  Output order is the reference's scan order (ascending
+// y, then x; reference src/orb.cpp:51-52) by construction: rows are prefix-summed, and inside a
+// row each lane owns 32 consecutive pixels.  A keypoint "has a descriptor" iff it is >= 16 px from
+// every edge (reference src/orb.cpp:156); its descriptor row is its rank among those.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowcount_kernel(const uint32_t* __restrict__ mask, int H, int W,
+                                                       int MW, long nrows, int2* __restrict__ rowcnt)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // frame * H + y
+    if (row >= nrows) return;
+    const int lane = lane_id();
+    const int y = (int)(row % H);
+    const bool yv = (y - 16 >= 0) && (y + 16 < H);
+    const uint32_t* mrow = mask + (size_t)row * MW;
+    int c = 0, cv = 0;
+    for (int w = lane; w < MW; w += 64) {
+        uint32_t bits = mrow[w];
+        c += __popc(bits);
+        if (yv) cv += __popc(bits & desc_column_bits(w, W));
+    }
+    c = wave_sum(c);
+    cv = wave_sum(cv);
+    if (lane == 0) rowcnt[row] = make_int2(c, cv);
+}
+
+void launch_rowcount(const FrameSet& fs, const uint32_t* mask, int2* rowcnt, hipStream_t s)
+{
+    long nrows = (long)fs.frames * fs.H;
+    hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, mask, fs.H,
+                       fs.W, mask_words(fs.W), nrows, rowcnt);
+}
+
+__global__ __launch_bounds__(256) void rowscan_kernel(const int2* __restrict__ rowcnt, int H,
+                                                      int2* __restrict__ rowoff,
+                                                      int32_t* __restrict__ counts)
+{
+    __shared__ int2 wsum[4];
+    const int f = blockIdx.x;
+    const int2* rc = rowcnt + (size_t)f * H;
+    int2* ro = rowoff + (size_t)f * H;
+    const int per = (H + 255) / 256;
+    const int r0 = threadIdx.x * per;
+    int a = 0, b = 0;
+    for (int r = r0; r < r0 + per && r < H; ++r) { a += rc[r].x; b += rc[r].y; }
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane);
+    if (lane == 63) wsum[wave] = make_int2(ia, ib);
+    __syncthreads();
+    int basea = 0, baseb = 0;
+    for (int w = 0; w < wave; ++w) { basea += wsum[w].x; baseb += wsum[w].y; }
+    int ea = basea + ia - a, eb = baseb + ib - b;  // exclusive prefix of this thread's chunk
+    for (int r = r0; r < r0 + per && r < H; ++r) {
+        ro[r] = make_int2(ea, eb);
+        ea += rc[r].x; eb += rc[r].y;
+    }
+    if (threadIdx.x == 255) {
+        counts[2 * f] = basea + ia;
+        counts[2 * f + 1] = baseb + ib;
+    }
+}
+
+void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_t* counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(rowscan_kernel, dim3(fs.frames), dim3(256), 0, s, rowcnt, fs.H, rowoff, counts);
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
+                                                   int MW, long nrows, const int2* __restrict__ rowcnt,
+                                                   const int2* __restrict__ rowoff, int cap,
+                                                   int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int2 rc = rowcnt[row];
+    if (rc.x == 0) return;
+    const int lane = lane_id();
+    const long f = row / H;
+    const int y = (int)(row - f * H);
+    const bool yv = (y - 16 >= 0) && (y + 16 < H);
+    const uint32_t* mrow = mask + (size_t)row * MW;
+    int2* xy = kpxy + (size_t)f * cap;
+    int32_t* slot = kpslot + (size_t)f * cap;
+    const int2 off = rowoff[row];
+    int base = off.x, basev = off.y;
+    for (int w0 = 0; w0 < MW; w0 += 64) {
+        const int w = w0 + lane;
+        uint32_t bits = w < MW ? mrow[w] : 0u;
+        const uint32_t vb = yv ? (bits & desc_column_bits(w, W)) : 0u;
+        const int c = __popc(bits), cv = __popc(vb);
+        const int ic = wave_incl_scan(c, lane), icv = wave_incl_scan(cv, lane);
+        int i = base + ic - c, iv = basev + icv - cv;
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1u;
+            const bool v = (vb >> b) & 1u;
+            if (i < cap) {
+                xy[i] = make_int2(32 * w + b, y);
+                slot[i] = v ? iv : -1;
+            }
+            ++i;
+            iv += v;
+        }
+        base += __shfl(ic, 63);
+        basev += __shfl(icv, 63);
+    }
+}
+
+void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
+                 int cap, int2* kpxy, int32_t* kpslot, hipStream_t s)
+{
+    long nrows = (long)fs.frames * fs.H;
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, mask, fs.H, fs.W,
+                       mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot);
+}
+
+// Descriptor rows for a caller-supplied keypoint list (any order): slot = rank among keypoints
+// that pass the 16-px border filter.  One workgroup walks the list in chunks of 1024.
+__global__ __launch_bounds__(1024) void slots_kernel(const int2* __restrict__ kpxy, int n, int H, int W,
+                                                     int32_t* __restrict__ kpslot,
+                                                     int32_t* __restrict__ counts)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        int v = 0;
+        if (i < n) {
+            const int2 p = kpxy[i];
+            v = (p.y - 16 >= 0) && (p.y + 16 < H) && (p.x - 16 >= 0) && (p.x + 16 < W);
+        }
+        const int iv = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = iv;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (i < n) kpslot[i] = v ? base + iv - 1 : -1;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + iv;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counts[0] = n; counts[1] = carry; }
+}
+
+void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_t* counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(slots_kernel, dim3(1), dim3(1024), 0, s, kpxy, n, H, W, kpslot, counts);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orientation + steered BRIEF, one wavefront per keypoint.
+//
+// Orientation (reference src/orb.cpp:110-140, :236-260): raw moments over the 31x31 square
+// clipped to the image.  The reference accumulates in double; all terms are integers below 2^21,
+// so int32 sums are exact.  angle = (float)(atan2(m01, m10) * (180/pi)), +360 (in double) if
+// negative, 0 when m00 == 0.
+//
+// Descriptor (reference src/orb.cpp:166-231): theta = angle * (pi/180) in double; each pattern
+// point is rotated with double cos/sin (two rounded products, one rounded sum), narrowed to
+// float, added to the float centre, rounded half-to-even; samples outside the image read 0.
+// Lane l of round r evaluates pair 64r + l; the wave's ballot is descriptor bytes 8r .. 8r+7.
+// ---------------------------------------------------------------------------------------------
+constexpr double ORB_PI = 3.1415926535897932384626433832795;
+
+__device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01)
+{
+    if (m00 == 0) return 0.0f;
+    double a = atan2((double)m01, (double)m10);
+    float ang = (float)(a * (180.0 / ORB_PI));
+    if (ang < 0) ang = (float)((double)ang + 360.0);
+    return ang;
+}
+
+__global__ __launch_bounds__(256) void orient_describe_kernel(
+    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
+    const float* __restrict__ angle_in, float* __restrict__ kp7, float* __restrict__ angle_out,
+    uint8_t* __restrict__ desc, int32_t* __restrict__ valid_idx)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int n = counts[2 * f];
+    n = n < cap ? n : cap;
+    if (i >= n) return;
+    const int lane = lane_id();
+    const uint8_t* img = gray + (size_t)f * H * W;
+    const size_t ki = (size_t)f * cap + i;
+    const int2 p = kpxy[ki];
+
+    float angle;
+    if (angle_in) {
+        angle = angle_in[ki];
+    } else {
+        int s00 = 0, s10 = 0, s01 = 0;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int q = lane + 64 * j;      // 0 .. 960 walks the 31x31 square row-major
+            const int v = q / 31, u = q - v * 31;
+            const int yy = p.y + v - 15, xx = p.x + u - 15;
+            if (q < 961 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const int I = img[(size_t)yy * W + xx];
+                s00 += I;
+                s10 += (u - 15) * I;
+                s01 += (v - 15) * I;
+            }
+        }
+        s00 = wave_sum(s00);
+        s10 = wave_sum(s10);
+        s01 = wave_sum(s01);
+        angle = angle_from_moments(s00, s10, s01);
+    }
+    if (angle_out && lane == 0) angle_out[ki] = angle;
+    if (kp7 && lane < 7) {
+        // [x, y, size, angle, response, octave, class_id] (reference src/main_interface.cpp:46-52)
+        float v = lane == 0 ? (float)p.x : lane == 1 ? (float)p.y : lane == 2 ? 7.0f
+                : lane == 3 ? angle : lane == 6 ? -1.0f : 0.0f;
+        kp7[ki * 7 + lane] = v;
+    }
+
+    if (!desc) return;
+    const int slot = kpslot[ki];
+    if (slot < 0) return;
+    const double rad = (double)angle * (ORB_PI / 180.0);
+    const double c = cos(rad), s = sin(rad);
+    const float cx = (float)p.x, cy = (float)p.y;
+    unsigned long long* drow = reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + slot) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
+        const double x1 = (double)(int8_t)(q & 255u), y1 = (double)(int8_t)((q >> 8) & 255u);
+        const double x2 = (double)(int8_t)((q >> 16) & 255u), y2 = (double)(int8_t)(q >> 24);
+        const float x1r = (float)(x1 * c - y1 * s);
+        const float y1r = (float)(x1 * s + y1 * c);
+        const float x2r = (float)(x2 * c - y2 * s);
+        const float y2r = (float)(x2 * s + y2 * c);
+        const int px1 = __float2int_rn(cx + x1r), py1 = __float2int_rn(cy + y1r);
+        const int px2 = __float2int_rn(cx + x2r), py2 = __float2int_rn(cy + y2r);
+        int v1 = 0, v2 = 0;
+        if (py1 >= 0 && py1 < H && px1 >= 0 && px1 < W) v1 = img[(size_t)py1 * W + px1];
+        if (py2 >= 0 && py2 < H && px2 >= 0 && px2 < W) v2 = img[(size_t)py2 * W + px2];
+        const unsigned long long bal = __ballot(v1 < v2);
+        if (lane == 0) drow[r] = bal;
+    }
+    if (valid_idx && lane == 0) valid_idx[(size_t)f * cap + slot] = i;
+}
+
+void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
+                            const int32_t* counts, int cap, const float* angle_in, float* kp7,
+                            float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
+{
+    dim3 grid((cap + 3) / 4, fs.frames);
+    hipLaunchKernelGGL(orient_describe_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot,
+                       counts, cap, angle_in, kp7, angle_out, desc, valid_idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hamming top-2 (cv2.BFMatcher(NORM_HAMMING).knnMatch(q, t, 2); reference views.py:162).
+//
+// One query per lane, held in 8 VGPRs.  The train row is the same for all 64 lanes, so its 8
+// dwords are wave-uniform operands.  Per (query, train) pair: 8 XOR + 8 popcount-accumulate,
+// then key = (distance << 18) | trainIndex and a running top-2 of keys by unsigned min / med3.
+// Unsigned key order is (distance, trainIndex) lexicographic order, which is the order in which
+// OpenCV's insertion (strict '<' while scanning ascending train index) leaves its two slots.
+// The train axis can be split over blockIdx.z; partial (m1, m2) keys are merged afterwards.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void top2_insert(uint32_t& m1, uint32_t& m2, uint32_t key)
+{
+    // second smallest of {m1 <= m2, key} is their median; v_med3_u32 has no builtin.
+    uint32_t med;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));
+    m2 = med;
+    m1 = m1 < key ? m1 : key;
+}
+
+__device__ __forceinline__ void knn2_store(uint32_t m1, uint32_t m2, int32_t* idx, int32_t* dist,
+                                           uint8_t* good, size_t o)
+{
+    const int i1 = m1 == KEY_NONE ? -1 : (int)(m1 & 0x3FFFFu);
+    const int d1 = m1 == KEY_NONE ? -1 : (int)(m1 >> 18);
+    const int i2 = m2 == KEY_NONE ? -1 : (int)(m2 & 0x3FFFFu);
+    const int d2 = m2 == KEY_NONE ? -1 : (int)(m2 >> 18);
+    reinterpret_cast<int2*>(idx)[o] = make_int2(i1, i2);
+    reinterpret_cast<int2*>(dist)[o] = make_int2(d1, d2);
+    // d1 < 0.75 * d2 for integers <= 256  <=>  4*d1 < 3*d2 (reference views.py:168)
+    if (good) good[o] = (i2 >= 0 && 4 * d1 < 3 * d2) ? 1 : 0;
+}
+
+// popcount(q ^ t) over 256 bits as a chain of popcount-accumulate instructions
+// (v_bcnt_u32_b32 dst = popcount(src0) + src1).
+__device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uint32_t* __restrict__ t)
+{
+    uint32_t d = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint32_t x = q[w] ^ t[w];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+    }
+    return d;
+}
+
+template <bool PARTIAL>
+__global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ qdesc,
+                                                   const uint8_t* __restrict__ tdesc,
+                                                   const int32_t* __restrict__ counts,
+                                                   const int32_t* __restrict__ pairs, int cap,
+                                                   int nq_fixed, int nt_fixed, int splits,
+                                                   uint32_t* __restrict__ partial,
+                                                   int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                   uint8_t* __restrict__ good)
+{
+    const int pair = blockIdx.y;
+    int qf = 0, tf = 0, nq = nq_fixed, nt = nt_fixed;
+    if (counts) {
+        if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
+        else { qf = pair + 1; tf = pair; }
+        nq = counts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+        nt = counts[2 * tf + 1]; nt = nt < cap ? nt : cap;
+    }
+    const int q0 = blockIdx.x * 256;
+    if (q0 >= nq) return;
+    const int qi = q0 + threadIdx.x;
+    const bool active = qi < nq;
+
+    uint32_t q[8];
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(qdesc + ((size_t)qf * cap + (active ? qi : q0)) * 32);
+        const uint4 a = qp[0], b = qp[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+
+    const int chunk = (nt + splits - 1) / splits;
+    const int t0 = blockIdx.z * chunk;
+    int t1 = t0 + chunk; t1 = t1 < nt ? t1 : nt;
+    const uint32_t* __restrict__ tp = reinterpret_cast<const uint32_t*>(tdesc + (size_t)tf * cap * 32) + (size_t)t0 * 8;
+
+    uint32_t m1 = KEY_NONE, m2 = KEY_NONE;
+    int j = t0;
+    // Four train rows per trip so that their (scalar) loads are issued together.
+    for (; j + 4 <= t1; j += 4, tp += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            top2_insert(m1, m2, (hamming256(q, tp + 8 * u) << 18) | (uint32_t)(j + u));
+    }
+    for (; j < t1; ++j, tp += 8)
+        top2_insert(m1, m2, (hamming256(q, tp) << 18) | (uint32_t)j);
+    if (!active) return;
+    if (PARTIAL) {
+        const size_t o = (((size_t)pair * splits + blockIdx.z) * cap + qi);
+        reinterpret_cast<uint2*>(partial)[o] = make_uint2(m1, m2);
+    } else {
+        knn2_store(m1, m2, idx, dist, good, (size_t)pair * cap + qi);
+    }
+}
+
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ pairs, int cap,
+                                                         int nq_fixed, int splits,
+                                                         const uint32_t* __restrict__ partial,
+                                                         int32_t* __restrict__ idx,
+                                                         int32_t* __restrict__ dist,
+                                                         uint8_t* __restrict__ good)
+{
+    const int pair = blockIdx.y;
+    int nq = nq_fixed;
+    if (counts) {
+        const int qf = pairs ? pairs[2 * pair] : pair + 1;
+        nq = counts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+    }
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t m1 = KEY_NONE, m2 = KEY_NONE;
+    for (int z = 0; z < splits; ++z) {
+        const uint2 k = reinterpret_cast<const uint2*>(partial)[((size_t)pair * splits + z) * cap + qi];
+        if (k.x != KEY_NONE) top2_insert(m1, m2, k.x);
+        if (k.y != KEY_NONE) top2_insert(m1, m2, k.y);
+    }
+    knn2_store(m1, m2, idx, dist, good, (size_t)pair * cap + qi);
+}
+
+// Lowe ratio filter with ordered compaction (reference views.py:163-171): query i is kept iff
+// dist0 < 0.75 * dist1 (4*d0 < 3*d1 in integers); kept rows keep query order.  One workgroup
+// walks the queries in chunks of 1024.  A query with a missing neighbour makes count[0] = -1.
+__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ dist, int nq,
+                                                             int32_t* __restrict__ good_q,
+                                                             int32_t* __restrict__ good_t2,
+                                                             int32_t* __restrict__ good_t1,
+                                                             int32_t* __restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    __shared__ int bad;
+    if (threadIdx.x == 0) { carry = 0; bad = 0; }
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < nq; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        int keep = 0;
+        int2 id = make_int2(0, 0);
+        if (i < nq) {
+            id = reinterpret_cast<const int2*>(idx)[i];
+            const int2 d = reinterpret_cast<const int2*>(dist)[i];
+            if (id.x < 0 || id.y < 0) bad = 1;
+            else keep = 4 * d.x < 3 * d.y;
+        }
+        const int ik = wave_incl_scan(keep, lane);
+        if (lane == 63) wsum[wave] = ik;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (keep) {
+            const int o = base + ik - 1;
+            good_q[o] = i;
+            good_t2[o] = id.y;
+            good_t1[o] = id.x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + ik;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = bad ? -1 : carry;
+}
+
+void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32_t* good_q,
+                          int32_t* good_t2, int32_t* good_t1, int32_t* count, hipStream_t s)
+{
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, idx, dist, nq, good_q, good_t2,
+                       good_t1, count);
+}
+
+void launch_knn2(const Knn2Args& a, hipStream_t s)
+{
+    const int nqmax = a.counts ? a.cap : a.nq_fixed;
+    dim3 grid((nqmax + 255) / 256, a.npairs, a.splits);
+    if (a.splits > 1)
+        hipLaunchKernelGGL(knn2_kernel<true>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.counts, a.pairs,
+                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
+    else
+        hipLaunchKernelGGL(knn2_kernel<false>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.counts, a.pairs,
+                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
+}
+
+void launch_knn2_merge(const Knn2Args& a, hipStream_t s)
+{
+    const int nqmax = a.counts ? a.cap : a.nq_fixed;
+    dim3 grid((nqmax + 255) / 256, a.npairs);
+    hipLaunchKernelGGL(knn2_merge_kernel, grid, dim3(256), 0, s, a.counts, a.pairs, a.cap, a.nq_fixed,
+                       a.splits, a.partial, a.idx, a.dist, a.good);
+}
+
+}  // namespace orbamd

@@ -1,0 +1,67 @@
+// orb_internal.h -- declarations shared by the kernel file and the C-ABI file of liborbamd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbamd {
+
+// Mask geometry: one bit per pixel, bit (x & 31) of 32-bit word (x >> 5); rows padded to whole words.
+static inline int mask_words(int W) { return (W + 31) >> 5; }
+
+// Frame-strided views used by the batch kernels (all device pointers).
+struct FrameSet {
+    const uint8_t* gray;   // [frames][H][W]
+    int frames, H, W;
+};
+
+struct ExtractBuffers {
+    uint32_t* mask;     // [frames][H][MW]
+    int2* rowcnt;       // [frames][H]   (all, valid) keypoints in the row
+    int2* rowoff;       // [frames][H]   exclusive prefix of rowcnt within the frame
+    int2* kpxy;         // [frames][cap] (x, y)
+    int32_t* kpslot;    // [frames][cap] descriptor row of the keypoint, -1 if it has none
+};
+
+// Kernel launchers (enqueue on `s`, no synchronisation, no allocation).
+void launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long npix, hipStream_t s);
+void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint32_t seed, int cell,
+                  int density_thr, hipStream_t s);
+void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s);
+void launch_rowcount(const FrameSet& fs, const uint32_t* mask, int2* rowcnt, hipStream_t s);
+void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_t* counts, hipStream_t s);
+void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
+                 int cap, int2* kpxy, int32_t* kpslot, hipStream_t s);
+// Orientation (+ keypoint rows) and descriptors for keypoints listed in kpxy/kpslot.
+//   counts  [frames][2] device; keypoints processed per frame = min(counts[f][0], cap)
+//   kp7     [frames][cap][7] or NULL;  angle_out [frames][cap] or NULL
+//   angle_in: when non-NULL the orientation step is skipped and these angles are used
+//   desc    [frames][cap][32] or NULL (then no descriptors are computed)
+void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
+                            const int32_t* counts, int cap, const float* angle_in, float* kp7,
+                            float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s);
+
+struct Knn2Args {
+    const uint8_t* qdesc;     // query descriptor base
+    const uint8_t* tdesc;     // train descriptor base
+    const int32_t* counts;    // [frames][2] or NULL
+    const int32_t* pairs;     // [npairs][2] or NULL (consecutive)
+    int npairs;
+    int cap;                  // rows per frame in qdesc/tdesc and per pair in the outputs
+    int nq_fixed, nt_fixed;   // used when counts == NULL
+    int splits;               // train-axis splits (>= 1)
+    uint32_t* partial;        // [npairs][splits][cap][2] packed keys when splits > 1
+    int32_t* idx;             // [npairs][cap][2]
+    int32_t* dist;            // [npairs][cap][2]
+    uint8_t* good;            // [npairs][cap] or NULL
+};
+// Descriptor rows (rank among keypoints >= 16 px from every edge) for a caller-supplied list;
+// counts[0] = n, counts[1] = number of descriptor rows.
+void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_t* counts, hipStream_t s);
+// Ordered compaction of the ratio test over one query set; count[0] = kept rows, or -1 when a
+// query has fewer than two neighbours.
+void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32_t* good_q,
+                          int32_t* good_t2, int32_t* good_t1, int32_t* count, hipStream_t s);
+void launch_knn2(const Knn2Args& a, hipStream_t s);
+void launch_knn2_merge(const Knn2Args& a, hipStream_t s);
+
+}  // namespace orbamd
