@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORB front-end hot path: frames/sec through FAST + orientation + BRIEF + Hamming
+top-2 matching (frame f against f-1) on synthetic 1920x1080 frame batches resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the whole path over this rank's batch of `--frames` frames (default 1000,
+~5k keypoints each): extract every frame, match every consecutive pair, and (N > 1) receive the
+previous rank's last frame over RCCL send/recv and match the seam pair.  Ranks own contiguous
+ranges of one long sequence (weak scaling: `--frames` per GPU).
+
+Rank 0 prints ONE JSON line.  Besides the throughput it carries
+  roofline      the dominant kernel's achieved rate against its bound (measured live with HIP events
+                on the launch stream in extra, untimed-for-`value` steps),
+  rooflines     the same for every kernel of the path,
+  cpu_baseline  the CPU restatement (oracle/) timed on a bounded sample of the same frames, rank 0,
+                N = 1 only; the same sample is also used to check the GPU results bit for bit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+# Integer VALU peak: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s (the figure
+# behind the 157.3 TFLOP/s FP32 vector peak, which counts an FMA as two operations).
+INT_VALU_PEAK_TOPS = 78.6
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
+    ap.add_argument("--preset", default="1080p", choices=["480p", "1080p", "4k"])
+    ap.add_argument("--cap", type=int, default=0, help="keypoint capacity per frame (0 = by preset)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-kernel HIP events")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from visual_slam_amd import synth
+    from visual_slam_amd.engine import OrbEngine
+    from visual_slam_amd.scheduler import FrameRangeScheduler, unpack_boundary
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    P = synth.PRESETS[args.preset]
+    H, W = P["H"], P["W"]
+    cap = args.cap or {"480p": 4096, "1080p": 8192, "4k": 32768}[args.preset]
+    F = args.frames
+    eng = OrbEngine(local_rank, cap=cap)
+    gray = eng.synth_frames(F, H, W, first_frame=rank * F, cell=P["cell"], density=P["density"])
+    feat = eng.alloc_features(F)
+    matches = eng.alloc_matches(F - 1)
+    seam = eng.alloc_matches(1)
+    sched = FrameRangeScheduler(eng, rank, world, with_keypoints=True)
+
+    def step():
+        eng.extract_batch(gray, out=feat)
+        reqs, rbuf = sched.exchange(feat)
+        eng.match_consecutive(feat, out=matches)
+        for r in reqs:
+            r.wait()
+        if rbuf is not None:
+            b = unpack_boundary(rbuf, cap, True)
+            eng.match_cross(feat, 0, b.desc, b.counts, out=seam)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * F * args.steps / dt
+
+    # ---- per-kernel timing (HIP events on the launch stream), untimed for `value` ------------
+    eng.ctx.timing_enable(True)
+    eng.ctx.timing_reset()
+    for _ in range(max(1, args.profile_steps)):
+        step()
+    torch.cuda.synchronize()
+    timing = eng.ctx.timing_read()
+    eng.ctx.timing_enable(False)
+
+    counts = feat.counts.cpu().numpy().astype(np.int64)
+    n = np.minimum(counts[:, 0], cap)
+    nv = np.minimum(counts[:, 1], cap)
+    MW8 = (W + 7) // 8
+    alg = {
+        # bytes per launch (one launch covers the rank's whole batch)
+        "fast_mask": ("hbm", float(F * (H * W + H * MW8 + 4 * H))),
+        "rowcount": ("hbm", float(F * (H * MW8 + 8 * H))),
+        "rowscan": ("hbm", float(F * (16 * H + 8))),
+        "emit": ("hbm", float(F * H * MW8 + 8 * n.sum())),
+        "orient_describe": ("hbm", float(np.minimum(H * W, 1849 * n).sum() + (8 + 4 + 28) * n.sum() + 32 * nv.sum())),
+        # integer operations per launch: 8 XOR + 8 popcount-accumulate per descriptor pair
+        "knn2": ("int_valu", float(16 * (nv[1:] * nv[:-1]).sum())),
+    }
+    rooflines = {}
+    for name, (bound, work) in alg.items():
+        ms, launches = timing.get(name, (0.0, 0))
+        if launches == 0:
+            continue
+        avg_s = ms / launches / 1e3
+        if bound == "hbm":
+            ach = work / avg_s / 1e9
+            rooflines[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": ms / launches}
+        else:
+            ach = work / avg_s / 1e12
+            rooflines[name] = {"bound": "int_valu", "achieved": ach, "peak": INT_VALU_PEAK_TOPS,
+                               "unit": "Tintop/s", "frac": ach / INT_VALU_PEAK_TOPS, "traffic": None,
+                               "avg_ms": ms / launches}
+    dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
+
+    # ---- CPU baseline + result check on a bounded sample (rank 0, N = 1) ------------------------
+    cpu = None
+    check = None
+    if rank == 0 and world == 1 and args.cpu_sample > 1:
+        import oracle
+        S = min(args.cpu_sample, F)
+        frames_host = gray[:S].cpu().numpy()
+        oracle.c.lib()
+        t0 = time.perf_counter()
+        ex = [oracle.c.extract_gray(frames_host[i]) for i in range(S)]
+        mt = [oracle.c.knn2(ex[i][1], ex[i - 1][1]) for i in range(1, S)]
+        cpu_dt = time.perf_counter() - t0
+        cpu = {"value": S / cpu_dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d of the %d frames of one step (%d extractions + %d consecutive-pair matches), "
+                         "oracle/orb_oracle.c at -O2, single thread" % (S, F, S, S - 1)}
+        ok = True
+        for i in range(S):
+            kp, desc, vidx = feat.frame(i)
+            ok &= np.array_equal(kp.view(np.uint32), ex[i][0].view(np.uint32))
+            ok &= np.array_equal(desc, ex[i][1]) and np.array_equal(vidx, ex[i][2])
+            if i:
+                idx, dst, _ = matches.pair(i - 1, len(desc))
+                ok &= np.array_equal(idx, mt[i - 1][0]) and np.array_equal(dst, mt[i - 1][1])
+        check = bool(ok)
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec (FAST+BRIEF+match) @1080p" if args.preset == "1080p"
+                      else "frames/sec (FAST+BRIEF+match) @%s" % args.preset,
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d frame batch, %d frames per GPU, ~%d keypoints/frame, "
+                                   "detect+orient+describe every frame, Hamming top-2 + ratio flag for every "
+                                   "consecutive pair" % (W, H, F, int(round(n.mean()))),
+                       "frames_per_gpu": F, "keypoints_per_frame": float(n.mean()),
+                       "descriptors_per_frame": float(nv.mean()), "capacity_per_frame": cap,
+                       "parallelism": "contiguous frame ranges, %d rank(s), RCCL send/recv of the seam frame"
+                                      % world},
+            "roofline": rooflines.get(dominant),
+            "roofline_kernel": dominant,
+            "rooflines": rooflines,
+            "cpu_baseline": cpu,
+            "gpu_matches_cpu_on_sample": check,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if check is False:
+        sys.exit("bench: GPU results differ from the CPU restatement on the sample")
+
+
+if __name__ == "__main__":
+    main()

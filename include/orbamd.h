@@ -172,8 +172,16 @@ int orbamd_knn2_batch_dev(orbamd_ctx* ctx, const uint8_t* d_desc, const int32_t*
                           int frames, int cap, const int32_t* d_pairs, int npairs,
                           int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
 
-/* Top-2 matching of two descriptor sets in device memory (used for the frame pair that spans
- * two GPUs' frame ranges, after the boundary descriptors have been received). */
+/* One frame pair whose two frames live in different frame-strided buffers with device-side
+ * counts: query frame `qframe` of (d_qdesc, d_qcounts) against train frame `tframe` of
+ * (d_tdesc, d_tcounts), both with per-frame capacity `cap`.  This is the pair that spans two
+ * GPUs' frame ranges: the train side is the boundary frame received from the neighbouring GPU.
+ * Outputs as one pair of orbamd_knn2_batch_dev: d_idx/d_dist int32 [cap, 2], d_good uint8 [cap]. */
+int orbamd_knn2_cross_dev(orbamd_ctx* ctx, const uint8_t* d_qdesc, const int32_t* d_qcounts, int qframe,
+                          const uint8_t* d_tdesc, const int32_t* d_tcounts, int tframe, int cap,
+                          int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
+
+/* Top-2 matching of two plain descriptor sets in device memory with host-side sizes. */
 int orbamd_knn2_dev(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                     int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
 

@@ -258,9 +258,11 @@ long orc_extract(const uint8_t* gray, int H, int W, float* kp7, long cap, uint8_
  * ---------------------------------------------------------------------- */
 static inline int orc_hamming32(const uint8_t* a, const uint8_t* b)
 {
-    int d = 0;
-    for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
-    return d;
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
 void orc_knn2(const uint8_t* q, long nq, const uint8_t* t, long nt, int32_t* idx, int32_t* dist)

@@ -667,11 +667,36 @@ int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d
     Knn2Args a{};
     a.qdesc = d_desc;
     a.tdesc = d_desc;
-    a.counts = d_counts;
+    a.qcounts = d_counts;
+    a.tcounts = d_counts;
     a.pairs = d_pairs;
     a.npairs = npairs;
     a.cap = cap;
     a.splits = choose_splits(cap, cap, npairs);
+    a.idx = d_idx;
+    a.dist = d_dist;
+    a.good = d_good;
+    return run_knn2(c, a);
+}
+
+int orbamd_knn2_cross_dev(orbamd_ctx* c, const uint8_t* d_qdesc, const int32_t* d_qcounts, int qframe,
+                          const uint8_t* d_tdesc, const int32_t* d_tcounts, int tframe, int cap, int32_t* d_idx,
+                          int32_t* d_dist, uint8_t* d_good)
+{
+    CHK(enter(c));
+    if (!d_qdesc || !d_qcounts || !d_tdesc || !d_tcounts || !d_idx || !d_dist || qframe < 0 || tframe < 0 ||
+        cap <= 0 || cap > ORBAMD_MAX_TRAIN)
+        return ORBAMD_E_BADARG;
+    Knn2Args a{};
+    a.qdesc = d_qdesc;
+    a.tdesc = d_tdesc;
+    a.qcounts = d_qcounts;
+    a.tcounts = d_tcounts;
+    a.qframe0 = qframe - 1;  // the kernel's consecutive-pair rule is (p + 1 + qframe0, p + tframe0)
+    a.tframe0 = tframe;
+    a.npairs = 1;
+    a.cap = cap;
+    a.splits = choose_splits(cap, cap, 1);
     a.idx = d_idx;
     a.dist = d_dist;
     a.good = d_good;

@@ -597,20 +597,22 @@ __device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uin
 template <bool PARTIAL>
 __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ qdesc,
                                                    const uint8_t* __restrict__ tdesc,
-                                                   const int32_t* __restrict__ counts,
-                                                   const int32_t* __restrict__ pairs, int cap,
-                                                   int nq_fixed, int nt_fixed, int splits,
+                                                   const int32_t* __restrict__ qcounts,
+                                                   const int32_t* __restrict__ tcounts,
+                                                   const int32_t* __restrict__ pairs, int qframe0,
+                                                   int tframe0, int cap, int nq_fixed, int nt_fixed,
+                                                   int splits,
                                                    uint32_t* __restrict__ partial,
                                                    int32_t* __restrict__ idx, int32_t* __restrict__ dist,
                                                    uint8_t* __restrict__ good)
 {
     const int pair = blockIdx.y;
     int qf = 0, tf = 0, nq = nq_fixed, nt = nt_fixed;
-    if (counts) {
+    if (qcounts) {
         if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
-        else { qf = pair + 1; tf = pair; }
-        nq = counts[2 * qf + 1]; nq = nq < cap ? nq : cap;
-        nt = counts[2 * tf + 1]; nt = nt < cap ? nt : cap;
+        else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
+        nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+        nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
     }
     const int q0 = blockIdx.x * 256;
     if (q0 >= nq) return;
@@ -649,9 +651,9 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
     }
 }
 
-__global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ pairs, int cap,
-                                                         int nq_fixed, int splits,
+__global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ qcounts,
+                                                         const int32_t* __restrict__ pairs, int qframe0,
+                                                         int cap, int nq_fixed, int splits,
                                                          const uint32_t* __restrict__ partial,
                                                          int32_t* __restrict__ idx,
                                                          int32_t* __restrict__ dist,
@@ -659,9 +661,9 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restri
 {
     const int pair = blockIdx.y;
     int nq = nq_fixed;
-    if (counts) {
-        const int qf = pairs ? pairs[2 * pair] : pair + 1;
-        nq = counts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+    if (qcounts) {
+        const int qf = pairs ? pairs[2 * pair] : pair + 1 + qframe0;
+        nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
     }
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
@@ -727,22 +729,24 @@ void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32
 
 void launch_knn2(const Knn2Args& a, hipStream_t s)
 {
-    const int nqmax = a.counts ? a.cap : a.nq_fixed;
+    const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     dim3 grid((nqmax + 255) / 256, a.npairs, a.splits);
     if (a.splits > 1)
-        hipLaunchKernelGGL(knn2_kernel<true>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.counts, a.pairs,
-                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
+        hipLaunchKernelGGL(knn2_kernel<true>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.qcounts, a.tcounts,
+                           a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial,
+                           a.idx, a.dist, a.good);
     else
-        hipLaunchKernelGGL(knn2_kernel<false>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.counts, a.pairs,
-                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
+        hipLaunchKernelGGL(knn2_kernel<false>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.qcounts, a.tcounts,
+                           a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial,
+                           a.idx, a.dist, a.good);
 }
 
 void launch_knn2_merge(const Knn2Args& a, hipStream_t s)
 {
-    const int nqmax = a.counts ? a.cap : a.nq_fixed;
+    const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     dim3 grid((nqmax + 255) / 256, a.npairs);
-    hipLaunchKernelGGL(knn2_merge_kernel, grid, dim3(256), 0, s, a.counts, a.pairs, a.cap, a.nq_fixed,
-                       a.splits, a.partial, a.idx, a.dist, a.good);
+    hipLaunchKernelGGL(knn2_merge_kernel, grid, dim3(256), 0, s, a.qcounts, a.pairs, a.qframe0, a.cap,
+                       a.nq_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
 }
 
 }  // namespace orbamd

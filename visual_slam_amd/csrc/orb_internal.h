@@ -43,11 +43,13 @@ void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t*
 struct Knn2Args {
     const uint8_t* qdesc;     // query descriptor base
     const uint8_t* tdesc;     // train descriptor base
-    const int32_t* counts;    // [frames][2] or NULL
-    const int32_t* pairs;     // [npairs][2] or NULL (consecutive)
+    const int32_t* qcounts;   // [frames][2] of the query buffer, or NULL (then *_fixed sizes are used)
+    const int32_t* tcounts;   // [frames][2] of the train buffer (== qcounts for one batch)
+    const int32_t* pairs;     // [npairs][2] (query frame, train frame) or NULL = consecutive (p+1, p)
+    int qframe0, tframe0;     // added to the pair's frame numbers (single cross pair: pairs == NULL, npairs == 1)
     int npairs;
     int cap;                  // rows per frame in qdesc/tdesc and per pair in the outputs
-    int nq_fixed, nt_fixed;   // used when counts == NULL
+    int nq_fixed, nt_fixed;   // used when qcounts == NULL
     int splits;               // train-axis splits (>= 1)
     uint32_t* partial;        // [npairs][splits][cap][2] packed keys when splits > 1
     int32_t* idx;             // [npairs][cap][2]
