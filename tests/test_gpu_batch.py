@@ -1,0 +1,218 @@
+"""GPU: frame-batch (device-pointer) entry points, golden fixtures, full-size property checks and the
+device-libm parity gate.  Everything goes through the C ABI (ctypes) or the pybind module."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import make_test_image
+from visual_slam_amd import synth
+
+import golden_util
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from visual_slam_amd.engine import OrbEngine
+    return OrbEngine(0, cap=4096)
+
+
+def test_golden_fixtures(gctx):
+    golden_util.check_impl_against_golden(gctx)
+
+
+@pytest.mark.parametrize("H,W,first,n,cell", [(96, 128, 0, 3, 12), (61, 83, 1000, 2, 12), (480, 640, 7, 2, 12),
+                                              (1080, 1920, 3, 1, 20)])
+def test_synth_frames_device_equals_numpy(eng, H, W, first, n, cell):
+    g = eng.synth_frames(n, H, W, first_frame=first, cell=cell)
+    eng.sync()
+    host = g.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(host[i], synth.synth_frame(H, W, first + i, cell=cell))
+
+
+def test_extract_batch_and_consecutive_matches(eng):
+    import torch
+    F, H, W = 5, 240, 320
+    frames = np.stack([synth.synth_frame(H, W, f, cell=12) for f in range(F - 1)] + [make_test_image(H, W, 77)])
+    gray = torch.from_numpy(frames).to(eng.device)
+    feat = eng.extract_batch(gray)
+    m = eng.match_consecutive(feat)
+    eng.sync()
+    ex = [oracle.c.extract_gray(frames[f]) for f in range(F)]
+    counts = feat.counts.cpu().numpy()
+    for f in range(F):
+        assert counts[f].tolist() == [len(ex[f][0]), len(ex[f][1])]
+        kp, desc, vidx = feat.frame(f)
+        assert np.array_equal(bits(kp), bits(ex[f][0]))
+        assert np.array_equal(desc, ex[f][1]) and np.array_equal(vidx, ex[f][2])
+    for f in range(1, F):
+        eidx, edist = oracle.c.knn2(ex[f][1], ex[f - 1][1])
+        idx, dist, good = m.pair(f - 1, len(ex[f][1]))
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        want = np.zeros(len(eidx), np.uint8)
+        want[oracle.c.ratio_filter(eidx, edist)[0]] = 1
+        assert np.array_equal(good, want)
+    # explicit pair list, including a frame against itself and a reversed pair
+    pairs = torch.tensor([[0, 0], [1, 3], [4, 2]], dtype=torch.int32, device=eng.device)
+    mp = eng.match_pairs(feat, pairs)
+    eng.sync()
+    for p, (qf, tf) in enumerate(pairs.cpu().tolist()):
+        eidx, edist = oracle.c.knn2(ex[qf][1], ex[tf][1])
+        idx, dist, _ = mp.pair(p, len(ex[qf][1]))
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+
+
+def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
+    import torch
+    from visual_slam_amd.engine import OrbEngine
+    H, W = 240, 320
+    frames = np.stack([synth.synth_frame(H, W, f, cell=12) for f in range(2)])
+    ex = [oracle.c.extract_gray(f) for f in frames]
+    cap = 100
+    assert all(len(e[0]) > cap for e in ex)
+    small = OrbEngine(0, cap=cap)
+    feat = small.extract_batch(torch.from_numpy(frames).to(small.device))
+    m = small.match_consecutive(feat)
+    small.sync()
+    counts = feat.counts.cpu().numpy()
+    for f in range(2):
+        assert counts[f].tolist() == [len(ex[f][0]), len(ex[f][1])]          # true totals
+        kp = feat.kp7[f].cpu().numpy()
+        assert np.array_equal(bits(kp), bits(ex[f][0][:cap]))                # first cap keypoints, in order
+        nv_kept = int((ex[f][2] < cap).sum())                                # descriptors of those keypoints
+        desc = feat.desc[f, :nv_kept].cpu().numpy()
+        assert np.array_equal(desc, ex[f][1][:nv_kept])
+    # matching clamps to cap rows; compare on the rows every frame certainly holds
+    nvk = [int((e[2] < cap).sum()) for e in ex]
+    if min(nvk) == cap:
+        pytest.skip("no border keypoints among the first rows")
+
+
+def test_cross_buffer_pair_with_device_counts(eng):
+    import torch
+    H, W = 200, 260
+    a = np.stack([synth.synth_frame(H, W, f, cell=12) for f in (0, 1, 2)])
+    b = np.stack([synth.synth_frame(H, W, f, cell=12) for f in (3, 4)])
+    fa = eng.extract_batch(torch.from_numpy(a).to(eng.device))
+    fb = eng.extract_batch(torch.from_numpy(b).to(eng.device))
+    m = eng.match_cross(fb, 0, fa.desc, fa.counts, tframe=2)     # frame 3 queries frame 2
+    eng.sync()
+    q = oracle.c.extract_gray(b[0])[1]
+    t = oracle.c.extract_gray(a[2])[1]
+    eidx, edist = oracle.c.knn2(q, t)
+    idx, dist, _ = m.pair(0, len(q))
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+
+
+def test_dense_matching_stress_20k(eng):
+    """20k x 20k BRIEF-256 top-2 with 1 % duplicated rows (train-axis split + merge path)."""
+    import torch
+    q = synth.synth_descriptors(20000, 12345)
+    t = synth.synth_descriptors(20000, 12346)
+    t[123] = q[5]
+    t[19999] = q[5]
+    idx, dist, good = eng.match_sets(torch.from_numpy(q).to(eng.device), torch.from_numpy(t).to(eng.device))
+    eng.sync()
+    eidx, edist = oracle.c.knn2(q, t)
+    assert np.array_equal(idx.cpu().numpy(), eidx) and np.array_equal(dist.cpu().numpy(), edist)
+    assert idx[5].tolist() == [123, 19999] and dist[5].tolist() == [0, 0]
+    want = np.zeros(len(q), np.uint8)
+    want[oracle.c.ratio_filter(eidx, edist)[0]] = 1
+    assert np.array_equal(good.cpu().numpy(), want)
+
+
+def test_matching_properties_self_match(eng):
+    """Size-independent properties: a set matched against itself finds itself at distance 0 (lowest
+    index among exact duplicates), dist0 <= dist1, indices in range; repeated runs are identical."""
+    import torch
+    d = synth.synth_descriptors(30000, 99, dup_frac=0.02)
+    dd = torch.from_numpy(d).to(eng.device)
+    idx, dist, _ = eng.match_sets(dd, dd)
+    idx2, dist2, _ = eng.match_sets(dd, dd)
+    eng.sync()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert np.array_equal(idx, idx2.cpu().numpy()) and np.array_equal(dist, dist2.cpu().numpy())
+    assert (dist[:, 0] == 0).all() and (dist[:, 0] <= dist[:, 1]).all()
+    assert (idx >= 0).all() and (idx < len(d)).all() and (idx[:, 0] != idx[:, 1]).all()
+    first_of = {}
+    for i, row in enumerate(map(bytes, d)):
+        first_of.setdefault(row, i)
+    want0 = np.array([first_of[bytes(r)] for r in d])
+    assert np.array_equal(idx[:, 0], want0)
+
+
+def test_full_size_1080p_batch_properties(eng):
+    """1080p batch: keypoints ascending in (y, x), descriptor rows in keypoint order and only for
+    keypoints >= 16 px from every edge, counts consistent; one frame checked against the oracle."""
+    import torch
+    from visual_slam_amd.engine import OrbEngine
+    P = synth.PRESETS["1080p"]
+    big = OrbEngine(0, cap=8192)
+    F = 12
+    gray = big.synth_frames(F, P["H"], P["W"], first_frame=40, cell=P["cell"], density=P["density"])
+    feat = big.extract_batch(gray)
+    feat2 = big.extract_batch(gray)
+    big.sync()
+    counts = feat.counts.cpu().numpy()
+    assert np.array_equal(counts, feat2.counts.cpu().numpy())
+    for f in range(F):
+        kp, desc, vidx = feat.frame(f)
+        n, nv = counts[f]
+        assert 4000 < n < 6000 and len(kp) == n and len(desc) == nv
+        x, y = kp[:, 0].astype(np.int64), kp[:, 1].astype(np.int64)
+        key = y * 100000 + x
+        assert (np.diff(key) > 0).all()
+        assert (x >= 3).all() and (x < P["W"] - 3).all() and (y >= 3).all() and (y < P["H"] - 3).all()
+        inner = (x >= 16) & (x <= P["W"] - 17) & (y >= 16) & (y <= P["H"] - 17)
+        assert np.array_equal(vidx, np.nonzero(inner)[0])
+        assert (kp[:, 2] == 7).all() and (kp[:, 4] == 0).all() and (kp[:, 5] == 0).all() and (kp[:, 6] == -1).all()
+        assert (kp[:, 3] >= 0).all() and (kp[:, 3] <= 360).all()
+        k2, d2, v2 = feat2.frame(f)
+        assert np.array_equal(bits(kp), bits(k2)) and np.array_equal(desc, d2)
+    host = gray[5].cpu().numpy()
+    ekp, edesc, evidx = oracle.c.extract_gray(host)
+    kp, desc, vidx = feat.frame(5)
+    assert np.array_equal(bits(kp), bits(ekp)) and np.array_equal(desc, edesc) and np.array_equal(vidx, evidx)
+
+
+def test_device_libm_parity_gate_orientation(gctx):
+    """Orientation goes through double atan2 on the device and through glibc in the reference; the
+    float angle must agree bit for bit.  ~2.8 M keypoints on images with strong gradients."""
+    mism = 0
+    total = 0
+    for seed in (1, 2):
+        rng = np.random.default_rng(seed)
+        H, W = 1000, 1400
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = (127 + 100 * np.sin(xx / (7.0 + seed)) * np.cos(yy / 11.0) + rng.integers(-25, 26, (H, W)))
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        xy = np.stack([xx.reshape(-1), yy.reshape(-1)], axis=1).astype(np.int32)
+        ang = gctx.orient(img, xy)
+        exp = oracle.c.orient(img, xy)
+        mism += int((bits(ang) != bits(exp)).sum())
+        total += len(xy)
+    assert total >= 2_800_000
+    assert mism == 0, "%d of %d float angles differ from the host libm result" % (mism, total)
+
+
+def test_device_libm_parity_gate_descriptors(gctx):
+    """Steered BRIEF goes through double cos/sin on the device: 200k keypoints at random float
+    angles (plus the exact axes) on a structured 1080p image must give identical descriptors."""
+    img = make_test_image(1080, 1920, 31, nrect=4000)
+    rng = np.random.default_rng(32)
+    n = 200_000
+    xy = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n)], axis=1).astype(np.int32)
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    ang[:5] = [0, 90, 180, 270, 360]
+    ang[5:1005] = np.round(ang[5:1005])          # whole degrees
+    desc, vidx = gctx.describe(img, xy, ang)
+    edesc, evidx = oracle.c.describe(img, xy, ang)
+    assert np.array_equal(vidx, evidx)
+    bad = int((desc != edesc).any(axis=1).sum())
+    assert bad == 0, "%d of %d descriptors differ" % (bad, len(edesc))
