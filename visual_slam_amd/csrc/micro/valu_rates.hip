@@ -1,0 +1,95 @@
+// valu_rates.hip -- issue rate of individual VALU instructions on gfx950 (register-only loops,
+// 8 waves per SIMD on every CU).  Used to choose the instruction mix of the integer kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+#define DEFKERNEL(NAME, ASM)                                                              \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t* out, int iters, uint32_t seed) \
+    {                                                                                     \
+        uint32_t a[8];                                                                    \
+        for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 0x9E3779B9u;    \
+        uint32_t t = seed ^ blockIdx.x, u = seed * 3u;                                    \
+        for (int it = 0; it < iters; ++it) {                                              \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+                _Pragma("unroll") for (int w = 0; w < 8; ++w)                             \
+                    asm volatile(ASM : "+v"(a[w]) : "v"(t), "v"(u));                      \
+            }                                                                             \
+        }                                                                                 \
+        uint32_t s = 0;                                                                   \
+        for (int i = 0; i < 8; ++i) s += a[i];                                            \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                          \
+    }
+
+DEFKERNEL(xor_e32, "v_xor_b32_e32 %0, %1, %0")
+DEFKERNEL(xor_e64, "v_xor_b32_e64 %0, %1, %0")
+DEFKERNEL(add_e32, "v_add_u32_e32 %0, %1, %0")
+DEFKERNEL(min_u32, "v_min_u32_e32 %0, %1, %0")
+DEFKERNEL(bcnt, "v_bcnt_u32_b32 %0, %1, %0")
+DEFKERNEL(bcnt0, "v_bcnt_u32_b32 %0, %0, 0")
+DEFKERNEL(add3, "v_add3_u32 %0, %1, %2, %0")
+DEFKERNEL(lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
+DEFKERNEL(bfi, "v_bfi_b32 %0, %1, %2, %0")
+DEFKERNEL(and_or, "v_and_or_b32 %0, %0, %1, %2")
+DEFKERNEL(med3, "v_med3_u32 %0, %1, %2, %0")
+DEFKERNEL(min3, "v_min3_u32 %0, %1, %2, %0")
+DEFKERNEL(max3, "v_max3_u32 %0, %1, %2, %0")
+DEFKERNEL(perm, "v_perm_b32 %0, %1, %0, %2")
+DEFKERNEL(alignbyte, "v_alignbyte_b32 %0, %1, %0, 1")
+DEFKERNEL(mad_u24, "v_mad_u32_u24 %0, %1, %2, %0")
+DEFKERNEL(mul_u24, "v_mul_u32_u24_e32 %0, %1, %0")
+DEFKERNEL(sad_u8, "v_sad_u8 %0, %1, %2, %0")
+DEFKERNEL(pk_add_u16, "v_pk_add_u16 %0, %1, %0")
+DEFKERNEL(pk_min_u16, "v_pk_min_u16 %0, %1, %0")
+DEFKERNEL(pk_max_u16, "v_pk_max_u16 %0, %1, %0")
+DEFKERNEL(pk_sub_i16, "v_pk_sub_i16 %0, %1, %0")
+DEFKERNEL(dot4_u8, "v_dot4_u32_u8 %0, %1, %2, %0")
+DEFKERNEL(cmp_gt, "v_cmp_gt_u32_e32 vcc, %1, %0\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc")
+DEFKERNEL(cmp_sgpr, "v_cmp_gt_u32_e64 s[20:21], %1, %0")
+DEFKERNEL(cndmask, "v_cndmask_b32_e32 %0, %1, %0, vcc")
+DEFKERNEL(fma_f32, "v_fma_f32 %0, %1, %2, %0")
+DEFKERNEL(bfe, "v_bfe_u32 %0, %0, 3, 8")
+DEFKERNEL(mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+DEFKERNEL(add_sdwa, "v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
+DEFKERNEL(cmp_sdwa, "v_cmp_gt_u32_sdwa s[20:21], %1, %0 src0_sel:BYTE_1 src1_sel:BYTE_2")
+
+typedef void (*kern_t)(uint32_t*, int, uint32_t);
+
+int run(const char* name, kern_t k, int ops_per_stmt, uint32_t* d)
+{
+    const int blocks = 256 * 8, iters = 10000;
+    hipEvent_t a, b;
+    HIPOK(hipEventCreate(&a));
+    HIPOK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIPOK(hipEventRecord(a));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 12345u);
+        HIPOK(hipEventRecord(b));
+        HIPOK(hipEventSynchronize(b));
+        float ms = 0;
+        HIPOK(hipEventElapsedTime(&ms, a, b));
+        if (rep && ms < best) best = ms;
+    }
+    double instr = (double)blocks * 4 * iters * 32.0 * ops_per_stmt;  // wave-instructions
+    double per_simd_ns = best * 1e6 / (instr / 1024.0);
+    printf("%-14s %8.3f ms  %7.2f T lane-ops/s  %6.3f ns per wave-instr per SIMD\n", name, best,
+           instr * 64 / best / 1e9, per_simd_ns);
+    return 0;
+}
+
+#define RUN(NAME, N) if (run(#NAME, k_##NAME, N, d)) return 1;
+
+int main()
+{
+    uint32_t* d;
+    HIPOK(hipMalloc(&d, (size_t)256 * 8 * 256 * 4));
+    RUN(xor_e32, 1) RUN(xor_e64, 1) RUN(add_e32, 1) RUN(min_u32, 1) RUN(bcnt, 1) RUN(bcnt0, 1) RUN(add3, 1)
+    RUN(lshl_or, 1) RUN(bfi, 1) RUN(and_or, 1) RUN(med3, 1) RUN(min3, 1) RUN(max3, 1) RUN(perm, 1)
+    RUN(alignbyte, 1) RUN(mad_u24, 1) RUN(mul_u24, 1) RUN(sad_u8, 1) RUN(pk_add_u16, 1) RUN(pk_min_u16, 1)
+    RUN(pk_max_u16, 1) RUN(pk_sub_i16, 1) RUN(dot4_u8, 1) RUN(cmp_gt, 2) RUN(cmp_sgpr, 1) RUN(cndmask, 1)
+    RUN(fma_f32, 1) RUN(bfe, 1) RUN(mov_dpp, 1) RUN(add_sdwa, 1) RUN(cmp_sdwa, 1)
+    return 0;
+}
