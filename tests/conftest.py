@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch first: a process holds one HIP runtime, and torch must find the one it was built with
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -65,6 +65,30 @@ class OrbAmdError(RuntimeError):
         super().__init__(msg)
 
 
+def _prefer_torch_hip_runtime():
+    """liborbamd.so needs libamdhip64.so.7.  A process can hold only one HIP runtime: if PyTorch is
+    installed and is imported AFTER this library has pulled in the system runtime, torch finds a
+    runtime it was not built with and reports no GPU.  So when torch is installed (imported or not),
+    load ITS bundled runtime first; the dynamic loader then resolves our dependency to that copy.
+    Without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load liborbamd.so (built in-tree by `make`); raises if it is not there."""
     global _lib
@@ -73,6 +97,7 @@ def lib():
             raise ImportError(
                 "visual_slam_amd: %s not found -- build it with `make` at the repository root "
                 "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+        _prefer_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header and library disagree

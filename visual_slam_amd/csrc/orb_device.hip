@@ -18,6 +18,8 @@
 #include "orb_internal.h"
 #include "orb_pattern.h"
 
+#include <stdlib.h>
+
 #pragma clang fp contract(off)
 
 namespace orbamd {
@@ -582,31 +584,52 @@ __device__ __forceinline__ void knn2_store(uint32_t m1, uint32_t m2, int32_t* id
 }
 
 // popcount(q ^ t) over 256 bits as a chain of popcount-accumulate instructions
-// (v_bcnt_u32_b32 dst = popcount(src0) + src1).
+// (v_bcnt_u32_b32 dst = popcount(src0) + src1; the first link adds the inline constant 0).
 __device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uint32_t* __restrict__ t)
 {
-    uint32_t d = 0;
+    uint32_t d;
+    {
+        const uint32_t x = q[0] ^ t[0];
+        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+    }
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 1; w < 8; ++w) {
         const uint32_t x = q[w] ^ t[w];
         asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
     }
     return d;
 }
 
-template <bool PARTIAL>
-__global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ qdesc,
-                                                   const uint8_t* __restrict__ tdesc,
-                                                   const int32_t* __restrict__ qcounts,
-                                                   const int32_t* __restrict__ tcounts,
-                                                   const int32_t* __restrict__ pairs, int qframe0,
-                                                   int tframe0, int cap, int nq_fixed, int nt_fixed,
-                                                   int splits,
-                                                   uint32_t* __restrict__ partial,
-                                                   int32_t* __restrict__ idx, int32_t* __restrict__ dist,
-                                                   uint8_t* __restrict__ good)
+// QPL queries per lane (register tiling over the query axis: one train row fetched per QPL * 64
+// pairs), RPT train rows per trip (their scalar loads are issued together), BS threads per block.
+template <int QPL, int RPT, int BS, bool PARTIAL>
+__global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qdesc,
+                                                  const uint8_t* __restrict__ tdesc,
+                                                  const int32_t* __restrict__ qcounts,
+                                                  const int32_t* __restrict__ tcounts,
+                                                  const int32_t* __restrict__ pairs, int qframe0,
+                                                  int tframe0, int cap, int nq_fixed, int nt_fixed,
+                                                  int splits, int nbp, uint32_t* __restrict__ partial,
+                                                  int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                  uint8_t* __restrict__ good)
 {
-    const int pair = blockIdx.y;
+    // 1-D grid of npairs * splits * nbp work items (nbp = query blocks per pair, made odd by the
+    // launcher).  Workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, round-robin to
+    // its shader engines; a pair's empty query blocks (beyond its descriptor count) would otherwise
+    // land on the same engines for every pair.  The remap gives each XCD a contiguous run of work
+    // items (a pair's blocks share its train rows in that XCD's L2) and the odd period rotates the
+    // empty blocks over the engines.  Placement only affects speed, never results.
+    int pair, zsplit, qblk;
+    {
+        const uint32_t total = gridDim.x, id = blockIdx.x;
+        const uint32_t qd = total >> 3, rm = total & 7u, xcd = id & 7u, pos = id >> 3;
+        const uint32_t logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + pos;
+        const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
+        pair = (int)(logical / per_pair);
+        const uint32_t rem = logical - (uint32_t)pair * per_pair;
+        zsplit = (int)(rem / (uint32_t)nbp);
+        qblk = (int)(rem - (uint32_t)zsplit * (uint32_t)nbp);
+    }
     int qf = 0, tf = 0, nq = nq_fixed, nt = nt_fixed;
     if (qcounts) {
         if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
@@ -614,40 +637,52 @@ __global__ __launch_bounds__(256) void knn2_kernel(const uint8_t* __restrict__ q
         nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
         nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
     }
-    const int q0 = blockIdx.x * 256;
+    const int q0 = qblk * (BS * QPL);
     if (q0 >= nq) return;
-    const int qi = q0 + threadIdx.x;
-    const bool active = qi < nq;
 
-    uint32_t q[8];
-    {
-        const uint4* qp = reinterpret_cast<const uint4*>(qdesc + ((size_t)qf * cap + (active ? qi : q0)) * 32);
+    uint32_t q[QPL][8];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int qi = q0 + u * BS + threadIdx.x;
+        const uint4* qp = reinterpret_cast<const uint4*>(qdesc + ((size_t)qf * cap + (qi < nq ? qi : q0)) * 32);
         const uint4 a = qp[0], b = qp[1];
-        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
-        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+        q[u][0] = a.x; q[u][1] = a.y; q[u][2] = a.z; q[u][3] = a.w;
+        q[u][4] = b.x; q[u][5] = b.y; q[u][6] = b.z; q[u][7] = b.w;
     }
 
     const int chunk = (nt + splits - 1) / splits;
-    const int t0 = blockIdx.z * chunk;
+    const int t0 = zsplit * chunk;
     int t1 = t0 + chunk; t1 = t1 < nt ? t1 : nt;
     const uint32_t* __restrict__ tp = reinterpret_cast<const uint32_t*>(tdesc + (size_t)tf * cap * 32) + (size_t)t0 * 8;
 
-    uint32_t m1 = KEY_NONE, m2 = KEY_NONE;
-    int j = t0;
-    // Four train rows per trip so that their (scalar) loads are issued together.
-    for (; j + 4 <= t1; j += 4, tp += 32) {
+    uint32_t m1[QPL], m2[QPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            top2_insert(m1, m2, (hamming256(q, tp + 8 * u) << 18) | (uint32_t)(j + u));
+    for (int u = 0; u < QPL; ++u) { m1[u] = KEY_NONE; m2[u] = KEY_NONE; }
+    int j = t0;
+    for (; j + RPT <= t1; j += RPT, tp += 8 * RPT) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+#pragma unroll
+            for (int u = 0; u < QPL; ++u)
+                top2_insert(m1[u], m2[u], (hamming256(q[u], tp + 8 * r) << 18) | (uint32_t)(j + r));
+        }
     }
-    for (; j < t1; ++j, tp += 8)
-        top2_insert(m1, m2, (hamming256(q, tp) << 18) | (uint32_t)j);
-    if (!active) return;
-    if (PARTIAL) {
-        const size_t o = (((size_t)pair * splits + blockIdx.z) * cap + qi);
-        reinterpret_cast<uint2*>(partial)[o] = make_uint2(m1, m2);
-    } else {
-        knn2_store(m1, m2, idx, dist, good, (size_t)pair * cap + qi);
+    for (; j < t1; ++j, tp += 8) {
+#pragma unroll
+        for (int u = 0; u < QPL; ++u)
+            top2_insert(m1[u], m2[u], (hamming256(q[u], tp) << 18) | (uint32_t)j);
+    }
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) {
+        const int qi = q0 + u * BS + threadIdx.x;
+        if (qi < nq) {
+            if (PARTIAL) {
+                const size_t o = (((size_t)pair * splits + zsplit) * cap + qi);
+                reinterpret_cast<uint2*>(partial)[o] = make_uint2(m1[u], m2[u]);
+            } else {
+                knn2_store(m1[u], m2[u], idx, dist, good, (size_t)pair * cap + qi);
+            }
+        }
     }
 }
 
@@ -727,18 +762,28 @@ void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32
                        good_t1, count);
 }
 
-void launch_knn2(const Knn2Args& a, hipStream_t s)
+template <int QPL, int RPT, int BS>
+static void launch_knn2_variant(const Knn2Args& a, hipStream_t s)
 {
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
-    dim3 grid((nqmax + 255) / 256, a.npairs, a.splits);
+    const int nbp = ((nqmax + BS * QPL - 1) / (BS * QPL)) | 1;   // odd: see the remap in the kernel
+    dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
     if (a.splits > 1)
-        hipLaunchKernelGGL(knn2_kernel<true>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.qcounts, a.tcounts,
-                           a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial,
-                           a.idx, a.dist, a.good);
+        hipLaunchKernelGGL((knn2_kernel<QPL, RPT, BS, true>), grid, dim3(BS), 0, s, a.qdesc, a.tdesc, a.qcounts,
+                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
+                           a.partial, a.idx, a.dist, a.good);
     else
-        hipLaunchKernelGGL(knn2_kernel<false>, grid, dim3(256), 0, s, a.qdesc, a.tdesc, a.qcounts, a.tcounts,
-                           a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, a.partial,
-                           a.idx, a.dist, a.good);
+        hipLaunchKernelGGL((knn2_kernel<QPL, RPT, BS, false>), grid, dim3(BS), 0, s, a.qdesc, a.tdesc, a.qcounts,
+                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
+                           a.partial, a.idx, a.dist, a.good);
+}
+
+void launch_knn2(const Knn2Args& a, hipStream_t s)
+{
+    // Measured on MI355X (1080p batch, ~4.7k x 4.7k descriptors per pair): one query per lane, four
+    // train rows per trip and single-wave workgroups was the fastest of the tilings tried
+    // (more queries per lane or 256-thread workgroups were 1-40 % slower).
+    launch_knn2_variant<1, 4, 64>(a, s);
 }
 
 void launch_knn2_merge(const Knn2Args& a, hipStream_t s)
