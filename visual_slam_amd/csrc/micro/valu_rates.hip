@@ -55,6 +55,75 @@ DEFKERNEL(mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
 DEFKERNEL(add_sdwa, "v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")
 DEFKERNEL(cmp_sdwa, "v_cmp_gt_u32_sdwa s[20:21], %1, %0 src0_sel:BYTE_1 src1_sel:BYTE_2")
 
+DEFKERNEL(and_b32, "v_and_b32_e32 %0, %1, %0")
+DEFKERNEL(or_b32, "v_or_b32_e32 %0, %1, %0")
+DEFKERNEL(sub_u32, "v_sub_u32_e32 %0, %1, %0")
+DEFKERNEL(lshlrev, "v_lshlrev_b32_e32 %0, 3, %0")
+DEFKERNEL(lshrrev, "v_lshrrev_b32_e32 %0, 3, %0")
+DEFKERNEL(mov_b32, "v_mov_b32_e32 %0, %1")
+DEFKERNEL(max_u32, "v_max_u32_e32 %0, %1, %0")
+DEFKERNEL(mul_lo_u32, "v_mul_lo_u32 %0, %1, %0")
+DEFKERNEL(add_f32, "v_add_f32_e32 %0, %1, %0")
+DEFKERNEL(mul_f32, "v_mul_f32_e32 %0, %1, %0")
+DEFKERNEL(rndne_f32, "v_rndne_f32_e32 %0, %0")
+DEFKERNEL(cvt_i32_f32, "v_cvt_i32_f32_e32 %0, %0")
+DEFKERNEL(cvt_f32_i32, "v_cvt_f32_i32_e32 %0, %0")
+DEFKERNEL(lshl_add, "v_lshl_add_u32 %0, %0, 2, %1")
+DEFKERNEL(add_lshl, "v_add_lshl_u32 %0, %0, %1, 2")
+
+#define DEFKERNEL64(NAME, ASM)                                                            \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t* out, int iters, uint32_t seed) \
+    {                                                                                     \
+        double a[8];                                                                      \
+        for (int i = 0; i < 8; ++i) a[i] = 1.0 + 1e-9 * (seed * (threadIdx.x + 1) + i);   \
+        double t = 1.0 + 1e-12 * (seed ^ blockIdx.x), u = 1e-13;                          \
+        for (int it = 0; it < iters; ++it) {                                              \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+                _Pragma("unroll") for (int w = 0; w < 8; ++w)                             \
+                    asm volatile(ASM : "+v"(a[w]) : "v"(t), "v"(u));                      \
+            }                                                                             \
+        }                                                                                 \
+        double s = 0;                                                                     \
+        for (int i = 0; i < 8; ++i) s += a[i];                                            \
+        out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s;                                \
+    }
+DEFKERNEL64(mul_f64, "v_mul_f64 %0, %1, %0")
+DEFKERNEL64(add_f64, "v_add_f64 %0, %1, %0")
+DEFKERNEL64(fma_f64, "v_fma_f64 %0, %1, %2, %0")
+
+__global__ __launch_bounds__(256) void k_cvt_f32_f64(uint32_t* out, int iters, uint32_t seed)
+{
+    double a[8];
+    float f[8];
+    for (int i = 0; i < 8; ++i) { a[i] = 1.0 + 1e-9 * (seed * (threadIdx.x + 1) + i); f[i] = 0; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) asm volatile("v_cvt_f32_f64_e32 %0, %1" : "=v"(f[w]) : "v"(a[w]));
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += f[i];
+    out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s;
+}
+__global__ __launch_bounds__(256) void k_cvt_f64_i32(uint32_t* out, int iters, uint32_t seed)
+{
+    double a[8];
+    int f[8];
+    for (int i = 0; i < 8; ++i) { f[i] = seed * (threadIdx.x + 1) + i; a[i] = 0; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) asm volatile("v_cvt_f64_i32_e32 %0, %1" : "=v"(a[w]) : "v"(f[w]));
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s;
+}
+
 typedef void (*kern_t)(uint32_t*, int, uint32_t);
 
 int run(const char* name, kern_t k, int ops_per_stmt, uint32_t* d)
@@ -91,5 +160,9 @@ int main()
     RUN(alignbyte, 1) RUN(mad_u24, 1) RUN(mul_u24, 1) RUN(sad_u8, 1) RUN(pk_add_u16, 1) RUN(pk_min_u16, 1)
     RUN(pk_max_u16, 1) RUN(pk_sub_i16, 1) RUN(dot4_u8, 1) RUN(cmp_gt, 2) RUN(cmp_sgpr, 1) RUN(cndmask, 1)
     RUN(fma_f32, 1) RUN(bfe, 1) RUN(mov_dpp, 1) RUN(add_sdwa, 1) RUN(cmp_sdwa, 1)
+    RUN(and_b32, 1) RUN(or_b32, 1) RUN(sub_u32, 1) RUN(lshlrev, 1) RUN(lshrrev, 1) RUN(mov_b32, 1) RUN(max_u32, 1)
+    RUN(mul_lo_u32, 1) RUN(add_f32, 1) RUN(mul_f32, 1) RUN(rndne_f32, 1) RUN(cvt_i32_f32, 1) RUN(cvt_f32_i32, 1)
+    RUN(lshl_add, 1) RUN(add_lshl, 1) RUN(mul_f64, 1) RUN(add_f64, 1) RUN(fma_f64, 1)
+    RUN(cvt_f32_f64, 1) RUN(cvt_f64_i32, 1)
     return 0;
 }

@@ -9,7 +9,7 @@
 //   emit_kernel             ordered expansion of the bit mask into (x, y) lists (ballot-free
 //                           popcount + wave prefix; ascending y then x by construction)
 //   slots_kernel            descriptor row numbers for caller-supplied keypoint lists
-//   orient_describe_kernel  one wavefront per keypoint: 31x31 moments, atan2, steered BRIEF-256
+//   orient_describe_kernel  one wavefront per batch of keypoints: 31x31 moments, atan2, steered BRIEF-256
 //   knn2_kernel             Hamming top-2, one query per lane, train rows broadcast
 //   knn2_merge_kernel       merges train-axis partial results
 //
@@ -31,6 +31,19 @@ __constant__ __attribute__((aligned(16))) int8_t c_pairs[ORBAMD_PATTERN_PAIRS * 
 // small helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Work-item number of this workgroup in a 1-D grid, remapped so that each XCD walks a contiguous
+// run of items.  Workgroups are dealt round-robin to the 8 XCDs (and, inside an XCD, round-robin
+// to its shader engines), so with `id % 8` fixed per XCD the items id/8 of one XCD are consecutive
+// logical items.  Callers whose items come in groups where only a leading part has work (a frame's
+// keypoint batches, a pair's query blocks) make the group size ODD so that the idle items do not
+// fall on the same engines for every group.  Affects speed only, never results.
+__device__ __forceinline__ uint32_t xcd_contiguous_item()
+{
+    const uint32_t total = gridDim.x, id = blockIdx.x;
+    const uint32_t qd = total >> 3, rm = total & 7u, xcd = id & 7u, pos = id >> 3;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + pos;
+}
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
@@ -444,17 +457,25 @@ void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Orientation + steered BRIEF, one wavefront per keypoint.
+// Orientation + steered BRIEF.
 //
 // Orientation (reference src/orb.cpp:110-140, :236-260): raw moments over the 31x31 square
-// clipped to the image.  The reference accumulates in double; all terms are integers below 2^21,
+// clipped to the image.  The reference accumulates in double; all terms are integers below 2^23,
 // so int32 sums are exact.  angle = (float)(atan2(m01, m10) * (180/pi)), +360 (in double) if
 // negative, 0 when m00 == 0.
 //
 // Descriptor (reference src/orb.cpp:166-231): theta = angle * (pi/180) in double; each pattern
 // point is rotated with double cos/sin (two rounded products, one rounded sum), narrowed to
 // float, added to the float centre, rounded half-to-even; samples outside the image read 0.
-// Lane l of round r evaluates pair 64r + l; the wave's ballot is descriptor bytes 8r .. 8r+7.
+//
+// Work decomposition: one wavefront owns a batch of KPW consecutive keypoints and runs three
+// phases.  A: for each keypoint in turn, all 64 lanes sum its patch (wave-wide, DPP reduction) and
+// the totals are parked in the lane whose number is the keypoint's position in the batch.
+// B: every lane computes atan2 / cos / sin for ITS keypoint -- the double-precision library calls
+// cost thousands of cycles, so they run once per batch with 64 keypoints side by side instead of
+// once per keypoint with 64 lanes doing the same thing.  C: for each keypoint in turn, cos / sin /
+// centre are broadcast from its lane and lane l of round r evaluates test pair 64r + l; the wave's
+// ballot is descriptor bytes 8r .. 8r+7.
 // ---------------------------------------------------------------------------------------------
 constexpr double ORB_PI = 3.1415926535897932384626433832795;
 
@@ -467,32 +488,68 @@ __device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01)
     return ang;
 }
 
-__global__ __launch_bounds__(256) void orient_describe_kernel(
-    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
-    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
-    const float* __restrict__ angle_in, float* __restrict__ kp7, float* __restrict__ angle_out,
-    uint8_t* __restrict__ desc, int32_t* __restrict__ valid_idx)
+// Sum over the 64 lanes with DPP adds; the total lands in lane 63 and is returned wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v)
 {
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int n = counts[2 * f];
-    n = n < cap ? n : cap;
-    if (i >= n) return;
-    const int lane = lane_id();
-    const uint8_t* img = gray + (size_t)f * H * W;
-    const size_t ki = (size_t)f * cap + i;
-    const int2 p = kpxy[ki];
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ int wave_total(int v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row of 16 holds the row sum
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
-    float angle;
-    if (angle_in) {
-        angle = angle_in[ki];
+// Patch moments of one keypoint, all 64 lanes cooperating.  Returns wave-uniform totals.
+// Fast path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned frame): the 31 columns
+// x-15 .. x+15 lie inside 9 aligned dwords; lane = 9 * rowgroup + dword, seven row groups walk the
+// 31 rows in five steps.  Per dword: bytes outside the 31 columns are masked to zero, then
+// m00 += sum of bytes (v_sad_u8), m10' += bytes . (u + 16) (v_dot4_u32_u8), m01 += v * rowsum.
+__device__ __forceinline__ void patch_moments(const uint8_t* __restrict__ img, int H, int W, int x, int y,
+                                              int lane, bool dwords, int& t00, int& t10, int& t01)
+{
+    int s00 = 0, s10 = 0, s01 = 0;
+    if (dwords) {
+        const int r = (x - 15) & 3;
+        const int xa = (x - 15) - r;              // aligned start column (may be negative)
+        const int dw = lane % 9, rg = lane / 9;   // lane 63: rg = 7, never a valid row group
+        const int t0 = 4 * dw;                    // t = t0 + b is the column offset from xa; valid iff r <= t <= 30 + r
+        uint32_t mask = 0xFFFFFFFFu;
+        const int lo = r - t0;                    // bytes below lo are left of the patch
+        if (lo > 0) mask = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
+        const int hi = 30 + r - t0;               // last valid byte
+        if (hi < 3) mask &= hi < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - hi)));
+        // weights u + 16 = t - r + 1 per byte.  In the first dword the bytes left of the patch would
+        // get negative weights (their borrows would spill into valid bytes), so that word is the
+        // r = 0 pattern {1,2,3,4} shifted up by r bytes; elsewhere the base is >= 2.
+        const uint32_t wts = dw == 0 ? (0x04030201u << (8 * r))
+                                     : (uint32_t)(t0 - r + 1) * 0x01010101u + 0x03020100u;
+        const int gx = xa + t0;
+        const bool colok = rg < 7 && gx >= 0 && gx < W && mask != 0u;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int row = rg + 7 * it;
+            const int gy = y - 15 + row;
+            uint32_t pix = 0;
+            if (colok && row < 31 && gy >= 0 && gy < H)
+                pix = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + gx) & mask;
+            const int rs = (int)__builtin_amdgcn_sad_u8(pix, 0u, 0u);
+            s00 += rs;
+            s10 = (int)__builtin_amdgcn_udot4(pix, wts, (uint32_t)s10, false);
+            s01 += (row - 15) * rs;
+        }
+        s10 -= 16 * s00;
     } else {
-        int s00 = 0, s10 = 0, s01 = 0;
 #pragma unroll 4
         for (int j = 0; j < 16; ++j) {
             const int q = lane + 64 * j;      // 0 .. 960 walks the 31x31 square row-major
             const int v = q / 31, u = q - v * 31;
-            const int yy = p.y + v - 15, xx = p.x + u - 15;
+            const int yy = y + v - 15, xx = x + u - 15;
             if (q < 961 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
                 const int I = img[(size_t)yy * W + xx];
                 s00 += I;
@@ -500,53 +557,227 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
                 s01 += (v - 15) * I;
             }
         }
-        s00 = wave_sum(s00);
-        s10 = wave_sum(s10);
-        s01 = wave_sum(s01);
-        angle = angle_from_moments(s00, s10, s01);
     }
-    if (angle_out && lane == 0) angle_out[ki] = angle;
-    if (kp7 && lane < 7) {
-        // [x, y, size, angle, response, octave, class_id] (reference src/main_interface.cpp:46-52)
-        float v = lane == 0 ? (float)p.x : lane == 1 ? (float)p.y : lane == 2 ? 7.0f
-                : lane == 3 ? angle : lane == 6 ? -1.0f : 0.0f;
-        kp7[ki * 7 + lane] = v;
-    }
+    t00 = wave_total(s00);
+    t10 = wave_total(s10);
+    t01 = wave_total(s01);
+}
 
+// Staging of one keypoint's 43-row x 12-dword window (aligned start column xa, first row y0):
+// lane = 12 * rs + dw for lanes 0..59, row = rs + 5 * it.
+constexpr int PATCH_ROWS = 43, PATCH_DW = 12;
+
+__device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int H, int W, int xa, int y0,
+                                           int dw, int rs, uint32_t (&regs)[9])
+{
+    const int gx = xa + 4 * dw;
+    const bool colok = rs < 5 && gx >= 0 && gx < W;
+#pragma unroll
+    for (int it = 0; it < 9; ++it) {
+        const int row = rs + 5 * it, gy = y0 + row;
+        uint32_t v = 0;
+        if (colok && row < PATCH_ROWS && gy >= 0 && gy < H)
+            v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + gx);
+        regs[it] = v;
+    }
+}
+
+__device__ __forceinline__ void stage_write(uint32_t* lds, int dw, int rs, const uint32_t (&regs)[9])
+{
+    if (rs < 5) {
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int row = rs + 5 * it;
+            if (row < PATCH_ROWS) lds[row * PATCH_DW + dw] = regs[it];
+        }
+    }
+}
+
+template <int KPW>
+__global__ __launch_bounds__(256) void orient_describe_kernel(
+    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
+    const float* __restrict__ angle_in, float* __restrict__ kp7, float* __restrict__ angle_out,
+    uint8_t* __restrict__ desc, int32_t* __restrict__ valid_idx, int dwords, int nbf)
+{
+    // 1-D grid of frames * nbf workgroups, nbf (workgroups per frame) odd: see xcd_contiguous_item().
+    const uint32_t item = xcd_contiguous_item();
+    const int f = (int)(item / (uint32_t)nbf);
+    const int blk = (int)(item - (uint32_t)f * (uint32_t)nbf);
+    const int base = (blk * 4 + (threadIdx.x >> 6)) * KPW;
+    int n = counts[2 * f];
+    n = n < cap ? n : cap;
+    if (base >= n) return;
+    const int nk = (n - base) < KPW ? (n - base) : KPW;
+    const int lane = lane_id();
+    const uint8_t* img = gray + (size_t)f * H * W;
+    const size_t k0 = (size_t)f * cap + base;
+
+    // this lane's keypoint (position `lane` of the batch)
+    const bool mine = lane < nk;
+    const int2 p = mine ? kpxy[k0 + lane] : make_int2(0, 0);
+    const int slot = (mine && desc) ? kpslot[k0 + lane] : -1;
+
+    // ---- phase A: moments, one keypoint at a time ----
+    float angle = 0.0f;
+    if (angle_in) {
+        if (mine) angle = angle_in[k0 + lane];
+    } else {
+        int m00 = 0, m10 = 0, m01 = 0;
+        for (int j = 0; j < nk; ++j) {
+            const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+            int t00, t10, t01;
+            patch_moments(img, H, W, x, y, lane, dwords != 0, t00, t10, t01);
+            if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
+        }
+        // ---- phase B (first half): one atan2 per lane ----
+        angle = angle_from_moments(m00, m10, m01);
+    }
+    if (mine) {
+        if (angle_out) angle_out[k0 + lane] = angle;
+        if (kp7) {
+            // [x, y, size, angle, response, octave, class_id] (reference src/main_interface.cpp:46-52)
+            float* row = kp7 + (k0 + lane) * 7;
+            row[0] = (float)p.x; row[1] = (float)p.y; row[2] = 7.0f; row[3] = angle;
+            row[4] = 0.0f; row[5] = 0.0f; row[6] = -1.0f;
+        }
+        if (slot >= 0 && valid_idx) valid_idx[(size_t)f * cap + slot] = base + lane;
+    }
     if (!desc) return;
-    const int slot = kpslot[ki];
-    if (slot < 0) return;
+    if (__ballot(slot >= 0) == 0ull) return;   // (lanes beyond the batch carry slot = -1)
+
+    // ---- phase B (second half): one cos / sin per lane ----
     const double rad = (double)angle * (ORB_PI / 180.0);
     const double c = cos(rad), s = sin(rad);
-    const float cx = (float)p.x, cy = (float)p.y;
-    unsigned long long* drow = reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + slot) * 32);
+    const int c_lo = __double2loint(c), c_hi = __double2hiint(c);
+    const int s_lo = __double2loint(s), s_hi = __double2hiint(s);
+
+    // this lane's four test pairs (one per round), as doubles
+    double px1[4], py1[4], px2[4], py2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
-        const double x1 = (double)(int8_t)(q & 255u), y1 = (double)(int8_t)((q >> 8) & 255u);
-        const double x2 = (double)(int8_t)((q >> 16) & 255u), y2 = (double)(int8_t)(q >> 24);
-        const float x1r = (float)(x1 * c - y1 * s);
-        const float y1r = (float)(x1 * s + y1 * c);
-        const float x2r = (float)(x2 * c - y2 * s);
-        const float y2r = (float)(x2 * s + y2 * c);
-        const int px1 = __float2int_rn(cx + x1r), py1 = __float2int_rn(cy + y1r);
-        const int px2 = __float2int_rn(cx + x2r), py2 = __float2int_rn(cy + y2r);
-        int v1 = 0, v2 = 0;
-        if (py1 >= 0 && py1 < H && px1 >= 0 && px1 < W) v1 = img[(size_t)py1 * W + px1];
-        if (py2 >= 0 && py2 < H && px2 >= 0 && px2 < W) v2 = img[(size_t)py2 * W + px2];
-        const unsigned long long bal = __ballot(v1 < v2);
-        if (lane == 0) drow[r] = bal;
+        px1[r] = (double)(int8_t)(q & 255u);
+        py1[r] = (double)(int8_t)((q >> 8) & 255u);
+        px2[r] = (double)(int8_t)((q >> 16) & 255u);
+        py2[r] = (double)(int8_t)(q >> 24);
     }
-    if (valid_idx && lane == 0) valid_idx[(size_t)f * cap + slot] = i;
+
+    // ---- phase C: descriptors, one keypoint at a time ----
+    unsigned long long todo = __ballot(slot >= 0);
+    if (dwords) {
+        // The 512 samples of a keypoint fall in the 43x43 window around it (|rotated offset| <=
+        // 21.3).  Scattered byte gathers from global memory cost one cache line per lane; instead the
+        // window is staged into this wave's LDS slab with coalesced dword reads (rows of 12 aligned
+        // dwords = 48 bytes, zero where outside the image -- which is also what an out-of-image
+        // sample must read, reference src/orb.cpp:211-217) and the samples are gathered from LDS.
+        // The next keypoint's window is loaded into registers while this one is evaluated.
+        __shared__ uint32_t slab[4][2][PATCH_ROWS * PATCH_DW];
+        uint32_t* const lds0 = slab[threadIdx.x >> 6][0];
+        uint32_t* const lds1 = slab[threadIdx.x >> 6][1];
+        const int dw = lane % PATCH_DW, rs = lane / PATCH_DW;     // lanes 60..63 idle while staging
+        uint32_t regs[9];
+        int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        {
+            const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+            stage_load(img, H, W, (x - 21) & ~3, y - 21, dw, rs, regs);
+        }
+        int cur = 0;
+        while (true) {
+            uint32_t* const lds = cur ? lds1 : lds0;
+            stage_write(lds, dw, rs, regs);
+            const int xj = __builtin_amdgcn_readlane(p.x, j), yj = __builtin_amdgcn_readlane(p.y, j);
+            const int sj = __builtin_amdgcn_readlane(slot, j);
+            const double cj = __hiloint2double(__builtin_amdgcn_readlane(c_hi, j), __builtin_amdgcn_readlane(c_lo, j));
+            const double sn = __hiloint2double(__builtin_amdgcn_readlane(s_hi, j), __builtin_amdgcn_readlane(s_lo, j));
+            const bool more = todo != 0ull;
+            int jn = j;
+            if (more) {
+                jn = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int x = __builtin_amdgcn_readlane(p.x, jn), y = __builtin_amdgcn_readlane(p.y, jn);
+                stage_load(img, H, W, (x - 21) & ~3, y - 21, dw, rs, regs);
+            }
+            // A non-finite angle (possible only for caller-supplied angles) makes every coordinate
+            // NaN; the reference's cvRound then yields INT_MIN, outside the image: all samples read 0.
+            const bool finite = fabs(cj) <= 1.0 && fabs(sn) <= 1.0;
+            const float cx = (float)xj, cy = (float)yj;
+            const int xa = (xj - 21) & ~3, y0 = yj - 21;
+            const uint8_t* const pb = reinterpret_cast<const uint8_t*>(lds);
+            unsigned long long bal[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1r = (float)(px1[r] * cj - py1[r] * sn);
+                const float y1r = (float)(px1[r] * sn + py1[r] * cj);
+                const float x2r = (float)(px2[r] * cj - py2[r] * sn);
+                const float y2r = (float)(px2[r] * sn + py2[r] * cj);
+                const int ax = __float2int_rn(cx + x1r), ay = __float2int_rn(cy + y1r);
+                const int bx = __float2int_rn(cx + x2r), by = __float2int_rn(cy + y2r);
+                int i1 = (ay - y0) * (PATCH_DW * 4) + (ax - xa);
+                int i2 = (by - y0) * (PATCH_DW * 4) + (bx - xa);
+                if (!finite) { i1 = 0; i2 = 0; }
+                const int v1 = pb[i1], v2 = pb[i2];
+                bal[r] = __ballot(finite && v1 < v2);
+            }
+            // lanes 0..3 store one 8-byte word each: 32 contiguous bytes per descriptor
+            if (lane < 4) {
+                const unsigned long long w = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
+                reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + sj) * 32)[lane] = w;
+            }
+            if (!more) break;
+            j = jn;
+            cur ^= 1;
+        }
+    } else {
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int sj = __builtin_amdgcn_readlane(slot, j);
+            const double cj = __hiloint2double(__builtin_amdgcn_readlane(c_hi, j), __builtin_amdgcn_readlane(c_lo, j));
+            const double sn = __hiloint2double(__builtin_amdgcn_readlane(s_hi, j), __builtin_amdgcn_readlane(s_lo, j));
+            const bool finite = fabs(cj) <= 1.0 && fabs(sn) <= 1.0;
+            const float cx = (float)__builtin_amdgcn_readlane(p.x, j), cy = (float)__builtin_amdgcn_readlane(p.y, j);
+            unsigned long long bal[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1r = (float)(px1[r] * cj - py1[r] * sn);
+                const float y1r = (float)(px1[r] * sn + py1[r] * cj);
+                const float x2r = (float)(px2[r] * cj - py2[r] * sn);
+                const float y2r = (float)(px2[r] * sn + py2[r] * cj);
+                const int ax = __float2int_rn(cx + x1r), ay = __float2int_rn(cy + y1r);
+                const int bx = __float2int_rn(cx + x2r), by = __float2int_rn(cy + y2r);
+                int v1 = 0, v2 = 0;
+                if (finite && ay >= 0 && ay < H && ax >= 0 && ax < W) v1 = img[(size_t)ay * W + ax];
+                if (finite && by >= 0 && by < H && bx >= 0 && bx < W) v2 = img[(size_t)by * W + bx];
+                bal[r] = __ballot(v1 < v2);
+            }
+            if (lane < 4) {
+                const unsigned long long w = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
+                reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + sj) * 32)[lane] = w;
+            }
+        }
+    }
 }
 
 void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
                             const int32_t* counts, int cap, const float* angle_in, float* kp7,
                             float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
 {
-    dim3 grid((cap + 3) / 4, fs.frames);
-    hipLaunchKernelGGL(orient_describe_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot,
-                       counts, cap, angle_in, kp7, angle_out, desc, valid_idx);
+    const int dwords = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
+    // Big launches: 64 keypoints per wave (library calls amortised 64-fold).  Small launches
+    // (single frames): 16 per wave, so that a few thousand keypoints still spread over the chip.
+    if ((long)fs.frames * cap >= 64L * 8192) {
+        const int nbf = ((cap + 4 * 64 - 1) / (4 * 64)) | 1;
+        hipLaunchKernelGGL(orient_describe_kernel<64>, dim3((unsigned)((size_t)nbf * fs.frames)), dim3(256), 0, s,
+                           fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc,
+                           valid_idx, dwords, nbf);
+    } else {
+        const int nbf = ((cap + 4 * 16 - 1) / (4 * 16)) | 1;
+        hipLaunchKernelGGL(orient_describe_kernel<16>, dim3((unsigned)((size_t)nbf * fs.frames)), dim3(256), 0, s,
+                           fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc,
+                           valid_idx, dwords, nbf);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -614,16 +845,11 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
                                                   uint8_t* __restrict__ good)
 {
     // 1-D grid of npairs * splits * nbp work items (nbp = query blocks per pair, made odd by the
-    // launcher).  Workgroups are dealt round-robin to the 8 XCDs and, inside an XCD, round-robin to
-    // its shader engines; a pair's empty query blocks (beyond its descriptor count) would otherwise
-    // land on the same engines for every pair.  The remap gives each XCD a contiguous run of work
-    // items (a pair's blocks share its train rows in that XCD's L2) and the odd period rotates the
-    // empty blocks over the engines.  Placement only affects speed, never results.
+    // launcher, see xcd_contiguous_item()): a pair's blocks run on one XCD and share its train rows
+    // in that XCD's L2.
     int pair, zsplit, qblk;
     {
-        const uint32_t total = gridDim.x, id = blockIdx.x;
-        const uint32_t qd = total >> 3, rm = total & 7u, xcd = id & 7u, pos = id >> 3;
-        const uint32_t logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + pos;
+        const uint32_t logical = xcd_contiguous_item();
         const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
         pair = (int)(logical / per_pair);
         const uint32_t rem = logical - (uint32_t)pair * per_pair;
