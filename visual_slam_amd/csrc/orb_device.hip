@@ -201,16 +201,30 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 //
 // A pixel with its radius-3 circle inside the image is a corner iff 12 consecutive circle pixels
 // k = s .. s+11, s in 0..4 (the reference's run counter never wraps past k = 15), are all
-// >= centre + 20 or all <= centre - 20.  The reference's four-point pre-test (:65-68) is implied
-// by that condition, so it is used here only as a cheap early-out.
+// >= centre + 20 or all <= centre - 20.  Every such run contains k = 4 and k = 8 and one of k = 0 /
+// k = 12, so it contains an opposite compass pair: (N and S) or (E and W) of one class.  That is
+// the cheap screen used here; it is implied by the reference's own four-point pre-test (:65-68),
+// so screening with it cannot lose a corner.
 //
-// Tile: 128 x 16 outputs per 256-thread workgroup, staged in LDS with a 3-row / 4-column halo
-// (columns padded to 4 so global reads are whole aligned dwords).  One lane tests one pixel; the
-// wave's ballot is 64 consecutive mask bits.
+// Tile: 256 x 32 outputs per 256-thread workgroup, staged in LDS (3-row halo, one dword of column
+// halo each side, filled by aligned dword reads).  A wave walks 8 rows; a lane owns one dword = 4
+// horizontally adjacent pixels and keeps a 7-row register window (three LDS dword reads per row).
+//   Phase 1, per dword: v_sad_u8 gives sum |N_k - C_k| over the dword's 4 pixels; a pixel can only
+//     pass the compass screen through (N, S) if that sum and the S sum are both >= 20, likewise
+//     (E, W).  One max/min/compare decides for 4 pixels; passing dwords are pushed to list A.
+//   Phase 2a, per listed dword (one per lane): the compass screen proper, per byte position with
+//     SDWA byte selects; results are 64-bit lane masks combined on the scalar unit; passing
+//     pixels are pushed to list B.
+//   Phase 2b, per listed pixel (one per lane): the full 16-pixel test; hits are OR-ed into the
+//     tile's bit mask in LDS, which is written out coalesced at the end.
+// Lists live in LDS per wave and are filled with mbcnt ranks, so every stage after phase 1 runs
+// with all lanes busy however sparse the corners are.
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 128, FT_H = 16;
-constexpr int FT_LW = FT_W + 8;   // LDS row bytes (136 = 34 dwords)
-constexpr int FT_LH = FT_H + 6;   // LDS rows
+constexpr int FT_W = 256, FT_H = 32;
+constexpr int FT_PITCH = FT_W / 4 + 2;     // LDS row pitch in dwords (one halo dword each side)
+constexpr int FT_LW = FT_PITCH * 4;        // LDS row pitch in bytes
+constexpr int FT_LH = FT_H + 6;            // LDS rows
+constexpr int FT_ROWS_PER_WAVE = FT_H / 4;
 
 // Circle offsets in LDS bytes, k = 0 at (0,-3), clockwise (reference src/orb.cpp:43-48).
 __device__ __forceinline__ constexpr int circ_off(int k)
@@ -230,69 +244,168 @@ __device__ __forceinline__ bool run12(uint32_t m)
     return (m & 0x1Fu) != 0;
 }
 
+// Lane masks of "byte K of a >= b" (unsigned) and "byte K of a <= b" (signed; b may be negative).
+#define ORB_CMP_GE_BYTE(K, dst, a, b) \
+    asm("v_cmp_ge_u32_sdwa %0, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD" : "=s"(dst) : "v"(a), "v"(b))
+#define ORB_CMP_LE_BYTE(K, dst, a, b) \
+    asm("v_cmp_le_i32_sdwa %0, %1, %2 src0_sel:BYTE_" #K " src1_sel:DWORD" : "=s"(dst) : "v"(a), "v"(b))
+
+// Screen of byte position K of this lane's centre dword C against its compass neighbours.
+#define ORB_SCREEN_BYTE(K, C, N, S, E, Wd, cand)                                   \
+    {                                                                               \
+        const uint32_t p_ = ((C) >> (8 * (K))) & 255u;                              \
+        const uint32_t hi_ = p_ + 20u;                                              \
+        const int lo_ = (int)p_ - 20;                                               \
+        unsigned long long bn_, bs_, be_, bw_, dn_, ds_, de_, dw_;                  \
+        ORB_CMP_GE_BYTE(K, bn_, N, hi_); ORB_CMP_GE_BYTE(K, bs_, S, hi_);           \
+        ORB_CMP_GE_BYTE(K, be_, E, hi_); ORB_CMP_GE_BYTE(K, bw_, Wd, hi_);          \
+        ORB_CMP_LE_BYTE(K, dn_, N, lo_); ORB_CMP_LE_BYTE(K, ds_, S, lo_);           \
+        ORB_CMP_LE_BYTE(K, de_, E, lo_); ORB_CMP_LE_BYTE(K, dw_, Wd, lo_);          \
+        cand = (bn_ & bs_) | (be_ & bw_) | (dn_ & ds_) | (de_ & dw_);               \
+    }
+
+constexpr int FT_LIST = 512;   // entries per wave and list (flushed before they can overflow)
+
+// Push the lanes of `m` (a wave-uniform lane mask) onto a per-wave LDS list.
+__device__ __forceinline__ void list_push(uint16_t* list, int& count, unsigned long long m, int lane,
+                                          uint32_t value)
+{
+    if (m != 0ull) {   // wave-uniform
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if ((m >> lane) & 1ull) list[count + rank] = (uint16_t)value;
+        count += __popcll(m);
+    }
+}
+
+// Phase 2b: exact segment test for list entries [from, from + n), n <= 64, one per lane.
+// Entry = (row within the wave's strip) << 8 | (x within the tile).
+__device__ __forceinline__ void fast_exact_batch(const uint8_t* tile, uint32_t* mtile, const uint16_t* list,
+                                                 int from, int n, int lane, int r0, int x0, int y0, int H, int W)
+{
+    if (lane < n) {
+        const uint32_t e = list[from + lane];
+        const int rr = (int)(e >> 8), xl = (int)(e & 255u);
+        const int x = x0 + xl, y = y0 + r0 + rr;
+        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
+            const uint8_t* c = tile + (r0 + rr + 3) * FT_LW + xl + 4;
+            const int p = c[0];
+            const int hi = p + 20, lo = p - 20;
+            uint32_t mb = 0, md = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int v = c[circ_off(k)];
+                mb |= (uint32_t)(v >= hi) << k;
+                md |= (uint32_t)(v <= lo) << k;
+            }
+            if (run12(mb) || run12(md))
+                atomicOr(&mtile[(r0 + rr) * (FT_W / 32) + (xl >> 5)], 1u << (xl & 31));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
                                                         int W, uint32_t* __restrict__ mask, int MW,
                                                         int aligned4)
 {
-    __shared__ uint32_t tile32[FT_LH * (FT_LW / 4)];
+    __shared__ uint32_t tile32[FT_LH * FT_PITCH];                 // 10032 B
+    __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
+    __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
     const int f = blockIdx.z;
     const uint8_t* img = gray + (size_t)f * H * W;
     uint32_t* mfr = mask + (size_t)f * H * MW;
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
 
-    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += 256) {
-        int r = i / (FT_LW / 4), j = i - r * (FT_LW / 4);
-        int y = y0 - 3 + r, x = x0 - 4 + 4 * j;
-        uint32_t v = 0;
-        if (y >= 0 && y < H) {
-            const uint8_t* row = img + (size_t)y * W;
-            if (aligned4 && x >= 0 && x + 3 < W) {
-                v = *reinterpret_cast<const uint32_t*>(row + x);
-            } else {
+    // ---- phase 0: stage the tile; wave w takes tile rows w, w + 4, ...; lane = dword of the row ----
+    for (int r = wave; r < FT_LH; r += 4) {
+        const int y = y0 - 3 + r;
+        const bool rowok = y >= 0 && y < H;                     // wave-uniform
+        const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    int xx = x + b;
-                    if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
+        for (int part = 0; part < 2; ++part) {
+            const int j = part * 64 + lane;                     // dword within the LDS row
+            if (j < FT_PITCH) {
+                const int x = x0 - 4 + 4 * j;
+                uint32_t v = 0;
+                if (rowok) {
+                    if (aligned4 && x >= 0 && x + 3 < W) {
+                        v = *reinterpret_cast<const uint32_t*>(row + x);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int xx = x + b;
+                            if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
+                        }
+                    }
                 }
+                tile32[r * FT_PITCH + j] = v;
             }
         }
-        tile32[i] = v;
     }
+    mtile[threadIdx.x] = 0u;
     __syncthreads();
 
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        const int ly = wave * 4 + (it >> 1);
-        const int half = it & 1;
-        const int lx = half * 64 + lane;
-        const int x = x0 + lx, y = y0 + ly;
-        const uint8_t* c = tile + (ly + 3) * FT_LW + lx + 4;
-        const int p = c[0];
-        const int hi = p + 20, lo = p - 20;
-        const int n = c[circ_off(0)], e = c[circ_off(4)], s = c[circ_off(8)], w = c[circ_off(12)];
-        const int nb = (n >= hi) + (e >= hi) + (s >= hi) + (w >= hi);
-        const int nd = (n <= lo) + (e <= lo) + (s <= lo) + (w <= lo);
-        const bool inside = x >= 3 && x < W - 3 && y >= 3 && y < H - 3;
-        bool corner = false;
-        if (inside && (nb >= 3 || nd >= 3)) {
-            uint32_t mb = 0, md = 0;
+    const int r0 = wave * FT_ROWS_PER_WAVE;                 // first output row of this wave (tile-local)
+    uint16_t* const listA = lists[wave][0];
+    uint16_t* const listB = lists[wave][1];
+    int countA = 0, countB = 0;
+
+    // ---- phase 1: SAD screen, one dword (4 pixels) per lane ----
+    {
+        // rw[i] = dword of tile row r0 + i at this lane's column (output row rr uses rw[rr .. rr + 6])
+        uint32_t rw[FT_ROWS_PER_WAVE + 6];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                int v = c[circ_off(k)];
-                mb |= (uint32_t)(v >= hi) << k;
-                md |= (uint32_t)(v <= lo) << k;
-            }
-            corner = run12(mb) || run12(md);
+        for (int i = 0; i < FT_ROWS_PER_WAVE + 6; ++i) rw[i] = tile32[(r0 + i) * FT_PITCH + lane + 1];
+#pragma unroll
+        for (int rr = 0; rr < FT_ROWS_PER_WAVE; ++rr) {
+            const uint32_t C = rw[rr + 3], N = rw[rr], S = rw[rr + 6];
+            const uint32_t Cp = tile32[(r0 + rr + 3) * FT_PITCH + lane];
+            const uint32_t Cn = tile32[(r0 + rr + 3) * FT_PITCH + lane + 2];
+            const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3);    // pixels x+3 .. x+6
+            const uint32_t Wd = __builtin_amdgcn_alignbyte(C, Cp, 1);   // pixels x-3 .. x
+            const uint32_t sn = __builtin_amdgcn_sad_u8(N, C, 0u), ss = __builtin_amdgcn_sad_u8(S, C, 0u);
+            const uint32_t se = __builtin_amdgcn_sad_u8(E, C, 0u), sw = __builtin_amdgcn_sad_u8(Wd, C, 0u);
+            const uint32_t ns = sn < ss ? sn : ss, ew = se < sw ? se : sw;
+            const unsigned long long m = __ballot((ns > ew ? ns : ew) >= 20u);
+            list_push(listA, countA, m, lane, (uint32_t)((rr << 6) | lane));
         }
-        const unsigned long long bal = __ballot(corner);
-        if (lane == 0 && y < H) {
-            const int wi = (x0 + half * 64) >> 5;
-            uint32_t* mrow = mfr + (size_t)y * MW;
-            if (wi < MW) mrow[wi] = (uint32_t)bal;
-            if (wi + 1 < MW) mrow[wi + 1] = (uint32_t)(bal >> 32);
+    }
+
+    // ---- phase 2a: compass screen on the listed dwords, one per lane; 2b whenever B holds 64 ----
+    for (int i0 = 0; i0 < countA; i0 += 64) {
+        const int i = i0 + lane;
+        const bool act = i < countA;
+        const uint32_t e = act ? listA[i] : 0u;
+        const int rr = (int)(e >> 6), dw = (int)(e & 63u);
+        const uint32_t* rc = tile32 + (r0 + rr + 3) * FT_PITCH + dw;   // -> the dword left of C
+        const uint32_t Cp = rc[0], C = rc[1], Cn = rc[2];
+        const uint32_t N = rc[1 - 3 * FT_PITCH], S = rc[1 + 3 * FT_PITCH];
+        const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3);
+        const uint32_t Wd = __builtin_amdgcn_alignbyte(C, Cp, 1);
+        const unsigned long long live = __ballot(act);
+        unsigned long long cand[4];
+        ORB_SCREEN_BYTE(0, C, N, S, E, Wd, cand[0]);
+        ORB_SCREEN_BYTE(1, C, N, S, E, Wd, cand[1]);
+        ORB_SCREEN_BYTE(2, C, N, S, E, Wd, cand[2]);
+        ORB_SCREEN_BYTE(3, C, N, S, E, Wd, cand[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            list_push(listB, countB, cand[k] & live, lane, (uint32_t)((rr << 8) | (4 * dw + k)));
+        while (countB >= 64) {
+            countB -= 64;
+            fast_exact_batch(tile, mtile, listB, countB, 64, lane, r0, x0, y0, H, W);
         }
+    }
+    if (countB > 0) fast_exact_batch(tile, mtile, listB, 0, countB, lane, r0, x0, y0, H, W);
+    __syncthreads();
+
+    // ---- write the tile's mask words (FT_H rows x 8 words) ----
+    {
+        const int row = threadIdx.x >> 3, wq = threadIdx.x & 7;
+        const int y = y0 + row, wi = (x0 >> 5) + wq;
+        if (y < H && wi < MW) mfr[(size_t)y * MW + wi] = mtile[threadIdx.x];
     }
 }
 
