@@ -319,25 +319,42 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
     const int lane = lane_id(), wave = threadIdx.x >> 6;
 
     // ---- phase 0: stage the tile; wave w takes tile rows w, w + 4, ...; lane = dword of the row ----
-    for (int r = wave; r < FT_LH; r += 4) {
-        const int y = y0 - 3 + r;
-        const bool rowok = y >= 0 && y < H;                     // wave-uniform
-        const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
+    if (aligned4) {
+        // Rows are whole aligned dwords.  Lane l reads dword l of the LDS row (image x = x0 - 4 + 4l);
+        // lanes 0 and 1 also read dwords 64 and 65.  All loads of a wave are issued before the
+        // first one is consumed.
+        const int xa = x0 - 4 + 4 * lane, xb = x0 + 252 + 4 * lane;
+        const bool oka = xa >= 0 && xa < W, okb = lane < 2 && xb < W;
+        uint32_t va[(FT_LH + 3) / 4], vb[(FT_LH + 3) / 4];
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int j = part * 64 + lane;                     // dword within the LDS row
-            if (j < FT_PITCH) {
+        for (int it = 0; it < (FT_LH + 3) / 4; ++it) {
+            const int r = wave + 4 * it, y = y0 - 3 + r;
+            const bool rowok = r < FT_LH && y >= 0 && y < H;        // wave-uniform
+            const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
+            va[it] = (rowok && oka) ? *reinterpret_cast<const uint32_t*>(row + xa) : 0u;
+            vb[it] = (rowok && okb) ? *reinterpret_cast<const uint32_t*>(row + xb) : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < (FT_LH + 3) / 4; ++it) {
+            const int r = wave + 4 * it;
+            if (r < FT_LH) {
+                tile32[r * FT_PITCH + lane] = va[it];
+                if (lane < 2) tile32[r * FT_PITCH + 64 + lane] = vb[it];
+            }
+        }
+    } else {
+        for (int r = wave; r < FT_LH; r += 4) {
+            const int y = y0 - 3 + r;
+            const bool rowok = y >= 0 && y < H;
+            const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
+            for (int j = lane; j < FT_PITCH; j += 64) {
                 const int x = x0 - 4 + 4 * j;
                 uint32_t v = 0;
                 if (rowok) {
-                    if (aligned4 && x >= 0 && x + 3 < W) {
-                        v = *reinterpret_cast<const uint32_t*>(row + x);
-                    } else {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int xx = x + b;
-                            if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
-                        }
+                    for (int b = 0; b < 4; ++b) {
+                        const int xx = x + b;
+                        if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
                     }
                 }
                 tile32[r * FT_PITCH + j] = v;
