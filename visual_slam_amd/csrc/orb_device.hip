@@ -32,6 +32,11 @@ __constant__ __attribute__((aligned(16))) int8_t c_pairs[ORBAMD_PATTERN_PAIRS * 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Index of this wave inside its workgroup as a SCALAR.  threadIdx.x >> 6 is the same in all 64
+// lanes, but the compiler cannot prove it and would keep everything derived from it (row numbers,
+// row pointers, LDS slab addresses) in vector registers with per-lane 64-bit address arithmetic.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Work-item number of this workgroup in a 1-D grid, remapped so that each XCD walks a contiguous
 // run of items.  Workgroups are dealt round-robin to the 8 XCDs (and, inside an XCD, round-robin
 // to its shader engines), so with `id % 8` fixed per XCD the items id/8 of one XCD are consecutive
@@ -304,69 +309,83 @@ __device__ __forceinline__ void fast_exact_batch(const uint8_t* tile, uint32_t* 
     }
 }
 
-__global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
-                                                        int W, uint32_t* __restrict__ mask, int MW,
-                                                        int aligned4)
-{
-    __shared__ uint32_t tile32[FT_LH * FT_PITCH];                 // 10032 B
-    __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
-    __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
-    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
-    const int f = blockIdx.z;
-    const uint8_t* img = gray + (size_t)f * H * W;
-    uint32_t* mfr = mask + (size_t)f * H * MW;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+// Staging of one tile (aligned path): lane l reads dword l of each of this wave's LDS rows (image
+// x = x0 - 4 + 4l; wave w owns tile rows w, w + 4, ...); dwords 64 and 65 of all those rows come from
+// one extra load (lane = 2 * row step + side).  Loads are unconditional from clamped coordinates
+// and the value is zeroed afterwards where the true position is outside the image: no branches, and
+// every load of the wave is in flight at once -- and stays in flight across the evaluation of the
+// previous tile, because loading (to registers) and storing (to LDS) are separate steps.
+constexpr int FT_STEPS = (FT_LH + 3) / 4;
 
-    // ---- phase 0: stage the tile; wave w takes tile rows w, w + 4, ...; lane = dword of the row ----
-    if (aligned4) {
-        // Rows are whole aligned dwords.  Lane l reads dword l of the LDS row (image x = x0 - 4 + 4l);
-        // lanes 0 and 1 also read dwords 64 and 65.  All loads of a wave are issued before the
-        // first one is consumed.
-        const int xa = x0 - 4 + 4 * lane, xb = x0 + 252 + 4 * lane;
-        const bool oka = xa >= 0 && xa < W, okb = lane < 2 && xb < W;
-        uint32_t va[(FT_LH + 3) / 4], vb[(FT_LH + 3) / 4];
+struct FastStage {
+    uint32_t va[FT_STEPS];
+    uint32_t vb;
+};
+
+__device__ __forceinline__ void fast_stage_load(FastStage& st, const uint8_t* __restrict__ img, int H, int W,
+                                                int x0, int y0, int lane, int wave)
+{
+    const int xa = x0 - 4 + 4 * lane;
+    const int xac = xa < 0 ? 0 : (xa < W ? xa : W - 4);
+    const int hy = y0 - 3 + wave + 4 * (lane >> 1);
+    const int hyc = hy < 0 ? 0 : (hy < H ? hy : H - 1);
+    const int xb = x0 + 252 + 4 * (lane & 1);
+    const int xbc = xb < W ? xb : W - 4;
 #pragma unroll
-        for (int it = 0; it < (FT_LH + 3) / 4; ++it) {
-            const int r = wave + 4 * it, y = y0 - 3 + r;
-            const bool rowok = r < FT_LH && y >= 0 && y < H;        // wave-uniform
-            const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
-            va[it] = (rowok && oka) ? *reinterpret_cast<const uint32_t*>(row + xa) : 0u;
-            vb[it] = (rowok && okb) ? *reinterpret_cast<const uint32_t*>(row + xb) : 0u;
-        }
+    for (int it = 0; it < FT_STEPS; ++it) {
+        const int y = y0 - 3 + wave + 4 * it;                      // wave-uniform
+        const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
+        st.va[it] = *reinterpret_cast<const uint32_t*>(img + (uint32_t)(yc * W) + (uint32_t)xac);
+    }
+    st.vb = *reinterpret_cast<const uint32_t*>(img + (uint32_t)(hyc * W) + (uint32_t)xbc);
+}
+
+__device__ __forceinline__ void fast_stage_store(const FastStage& st, uint32_t* tile32, int H, int W, int x0,
+                                                 int y0, int lane, int wave)
+{
+    const int xa = x0 - 4 + 4 * lane;
+    const bool oka = xa >= 0 && xa < W;
+    const int hr = wave + 4 * (lane >> 1), hy = y0 - 3 + hr;
+    const int xb = x0 + 252 + 4 * (lane & 1);
+    const bool okb = hy >= 0 && hy < H && xb < W;
 #pragma unroll
-        for (int it = 0; it < (FT_LH + 3) / 4; ++it) {
-            const int r = wave + 4 * it;
-            if (r < FT_LH) {
-                tile32[r * FT_PITCH + lane] = va[it];
-                if (lane < 2) tile32[r * FT_PITCH + 64 + lane] = vb[it];
-            }
-        }
-    } else {
-        for (int r = wave; r < FT_LH; r += 4) {
-            const int y = y0 - 3 + r;
-            const bool rowok = y >= 0 && y < H;
-            const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
-            for (int j = lane; j < FT_PITCH; j += 64) {
-                const int x = x0 - 4 + 4 * j;
-                uint32_t v = 0;
-                if (rowok) {
+    for (int it = 0; it < FT_STEPS; ++it) {
+        const int r = wave + 4 * it, y = y0 - 3 + r;
+        const bool rowok = y >= 0 && y < H;                        // wave-uniform
+        if (r < FT_LH) tile32[r * FT_PITCH + lane] = (rowok && oka) ? st.va[it] : 0u;
+    }
+    if (lane < 2 * FT_STEPS && hr < FT_LH) tile32[hr * FT_PITCH + 64 + (lane & 1)] = okb ? st.vb : 0u;
+}
+
+// Staging for images whose rows are not whole aligned dwords: bytes assembled one by one.
+__device__ __forceinline__ void fast_stage_bytes(uint32_t* tile32, const uint8_t* __restrict__ img, int H,
+                                                 int W, int x0, int y0, int lane, int wave)
+{
+    for (int r = wave; r < FT_LH; r += 4) {
+        const int y = y0 - 3 + r;
+        const bool rowok = y >= 0 && y < H;
+        const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
+        for (int j = lane; j < FT_PITCH; j += 64) {
+            const int x = x0 - 4 + 4 * j;
+            uint32_t v = 0;
+            if (rowok) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int xx = x + b;
-                        if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
-                    }
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = x + b;
+                    if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
                 }
-                tile32[r * FT_PITCH + j] = v;
             }
+            tile32[r * FT_PITCH + j] = v;
         }
     }
-    mtile[threadIdx.x] = 0u;
-    __syncthreads();
+}
 
+// Phases 1, 2a, 2b for this wave's 8 rows of the staged tile.
+__device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t* mtile, uint16_t* listA,
+                                               uint16_t* listB, int lane, int wave, int x0, int y0, int H, int W)
+{
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
     const int r0 = wave * FT_ROWS_PER_WAVE;                 // first output row of this wave (tile-local)
-    uint16_t* const listA = lists[wave][0];
-    uint16_t* const listB = lists[wave][1];
     int countA = 0, countB = 0;
 
     // ---- phase 1: SAD screen, one dword (4 pixels) per lane ----
@@ -416,14 +435,42 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
         }
     }
     if (countB > 0) fast_exact_batch(tile, mtile, listB, 0, countB, lane, r0, x0, y0, H, W);
+}
+
+// One workgroup per tile.  (A persistent variant that walked a strip of tiles with two LDS buffers
+// and prefetched the next tile during evaluation was measured 25-60 % SLOWER on MI355X: the extra
+// registers and LDS cut the resident workgroups per CU from 8 to 5, which cost more memory-level
+// parallelism than the prefetch bought.)
+__global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
+                                                        int W, uint32_t* __restrict__ mask, int MW,
+                                                        int aligned4)
+{
+    __shared__ uint32_t tile32[FT_LH * FT_PITCH];                 // 10032 B
+    __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
+    __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
+    const int f = blockIdx.z;
+    const uint8_t* img = gray + (size_t)f * H * W;
+    uint32_t* mfr = mask + (size_t)f * H * MW;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int lane = lane_id(), wave = wave_id();
+
+    if (aligned4) {
+        FastStage st;
+        fast_stage_load(st, img, H, W, x0, y0, lane, wave);
+        fast_stage_store(st, tile32, H, W, x0, y0, lane, wave);
+    } else {
+        fast_stage_bytes(tile32, img, H, W, x0, y0, lane, wave);
+    }
+    mtile[threadIdx.x] = 0u;
     __syncthreads();
 
-    // ---- write the tile's mask words (FT_H rows x 8 words) ----
-    {
-        const int row = threadIdx.x >> 3, wq = threadIdx.x & 7;
-        const int y = y0 + row, wi = (x0 >> 5) + wq;
-        if (y < H && wi < MW) mfr[(size_t)y * MW + wi] = mtile[threadIdx.x];
-    }
+    fast_eval_tile(tile32, mtile, lists[wave][0], lists[wave][1], lane, wave, x0, y0, H, W);
+    __syncthreads();
+
+    // write the tile's mask words (FT_H rows x 8 words)
+    const int row = threadIdx.x >> 3, wq = threadIdx.x & 7;
+    const int y = y0 + row, wi = (x0 >> 5) + wq;
+    if (y < H && wi < MW) mfr[(size_t)y * MW + wi] = mtile[threadIdx.x];
 }
 
 void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
@@ -443,7 +490,7 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
 __global__ __launch_bounds__(256) void rowcount_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                        int MW, long nrows, int2* __restrict__ rowcnt)
 {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // frame * H + y
+    const long row = (long)blockIdx.x * 4 + wave_id();  // frame * H + y
     if (row >= nrows) return;
     const int lane = lane_id();
     const int y = (int)(row % H);
@@ -479,7 +526,7 @@ __global__ __launch_bounds__(256) void rowscan_kernel(const int2* __restrict__ r
     const int r0 = threadIdx.x * per;
     int a = 0, b = 0;
     for (int r = r0; r < r0 + per && r < H; ++r) { a += rc[r].x; b += rc[r].y; }
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = wave_id();
     int ia = wave_incl_scan(a, lane), ib = wave_incl_scan(b, lane);
     if (lane == 63) wsum[wave] = make_int2(ia, ib);
     __syncthreads();
@@ -506,7 +553,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
                                                    const int2* __restrict__ rowoff, int cap,
                                                    int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
 {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row = (long)blockIdx.x * 4 + wave_id();
     if (row >= nrows) return;
     const int2 rc = rowcnt[row];
     if (rc.x == 0) return;
@@ -560,7 +607,7 @@ __global__ __launch_bounds__(1024) void slots_kernel(const int2* __restrict__ kp
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = wave_id();
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + threadIdx.x;
         int v = 0;
@@ -734,7 +781,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
     const uint32_t item = xcd_contiguous_item();
     const int f = (int)(item / (uint32_t)nbf);
     const int blk = (int)(item - (uint32_t)f * (uint32_t)nbf);
-    const int base = (blk * 4 + (threadIdx.x >> 6)) * KPW;
+    const int base = (blk * 4 + wave_id()) * KPW;
     int n = counts[2 * f];
     n = n < cap ? n : cap;
     if (base >= n) return;
@@ -803,8 +850,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
         // sample must read, reference src/orb.cpp:211-217) and the samples are gathered from LDS.
         // The next keypoint's window is loaded into registers while this one is evaluated.
         __shared__ uint32_t slab[4][2][PATCH_ROWS * PATCH_DW];
-        uint32_t* const lds0 = slab[threadIdx.x >> 6][0];
-        uint32_t* const lds1 = slab[threadIdx.x >> 6][1];
+        uint32_t* const lds0 = slab[wave_id()][0];
+        uint32_t* const lds1 = slab[wave_id()][1];
         const int dw = lane % PATCH_DW, rs = lane / PATCH_DW;     // lanes 60..63 idle while staging
         uint32_t regs[9];
         int j = __builtin_ctzll(todo);
@@ -1082,7 +1129,7 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int32_t* __re
     __shared__ int bad;
     if (threadIdx.x == 0) { carry = 0; bad = 0; }
     __syncthreads();
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = wave_id();
     for (int i0 = 0; i0 < nq; i0 += 1024) {
         const int i = i0 + threadIdx.x;
         int keep = 0;
