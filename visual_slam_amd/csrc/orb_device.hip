@@ -226,7 +226,11 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 // with all lanes busy however sparse the corners are.
 // ---------------------------------------------------------------------------------------------
 constexpr int FT_W = 256, FT_H = 32;
-constexpr int FT_PITCH = FT_W / 4 + 2;     // LDS row pitch in dwords (one halo dword each side)
+constexpr int FT_PITCH = FT_W / 4 + 4;     // LDS row pitch in dwords: pixel x of a tile row sits at byte
+                                           // 16 + (x - x0); the left halo dword is at byte 12, the right
+                                           // halo dword (byte 272) falls into the next row's unused pad, so
+                                           // the 256-byte body of every row is 16-byte aligned
+constexpr int FT_X0 = 4;                   // dword index of pixel x0 within an LDS row
 constexpr int FT_LW = FT_PITCH * 4;        // LDS row pitch in bytes
 constexpr int FT_LH = FT_H + 6;            // LDS rows
 constexpr int FT_ROWS_PER_WAVE = FT_H / 4;
@@ -293,7 +297,7 @@ __device__ __forceinline__ void fast_exact_batch(const uint8_t* tile, uint32_t* 
         const int rr = (int)(e >> 8), xl = (int)(e & 255u);
         const int x = x0 + xl, y = y0 + r0 + rr;
         if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
-            const uint8_t* c = tile + (r0 + rr + 3) * FT_LW + xl + 4;
+            const uint8_t* c = tile + (r0 + rr + 3) * FT_LW + xl + 4 * FT_X0;
             const int p = c[0];
             const int hi = p + 20, lo = p - 20;
             uint32_t mb = 0, md = 0;
@@ -352,9 +356,64 @@ __device__ __forceinline__ void fast_stage_store(const FastStage& st, uint32_t* 
     for (int it = 0; it < FT_STEPS; ++it) {
         const int r = wave + 4 * it, y = y0 - 3 + r;
         const bool rowok = y >= 0 && y < H;                        // wave-uniform
-        if (r < FT_LH) tile32[r * FT_PITCH + lane] = (rowok && oka) ? st.va[it] : 0u;
+        if (r < FT_LH) tile32[r * FT_PITCH + FT_X0 - 1 + lane] = (rowok && oka) ? st.va[it] : 0u;
     }
-    if (lane < 2 * FT_STEPS && hr < FT_LH) tile32[hr * FT_PITCH + 64 + (lane & 1)] = okb ? st.vb : 0u;
+    if (lane < 2 * FT_STEPS && hr < FT_LH) tile32[hr * FT_PITCH + FT_X0 + 63 + (lane & 1)] = okb ? st.vb : 0u;
+}
+
+// Staging when rows are whole aligned 16-byte groups (W % 16 == 0, 16-byte-aligned frame): one load
+// instruction moves four tile rows (lane = 16 * row + 16-byte segment), three instructions cover
+// this wave's rows (row groups w, w + 4, w + 8); the halo dwords of all 38 rows are fetched by
+// waves 2 and 3 with one instruction each.  Same clamp-then-zero rule as above.
+struct FastStage16 {
+    uint4 v[3];
+    uint32_t h;
+};
+
+__device__ __forceinline__ void fast_stage16_load(FastStage16& st, const uint8_t* __restrict__ img, int H,
+                                                  int W, int x0, int y0, int lane, int wave)
+{
+    const int x = x0 + 16 * (lane & 15);
+    const int xc = x < W ? x : W - 16;
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+        const int y = y0 - 3 + 4 * (wave + 4 * gi) + (lane >> 4);
+        const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
+        st.v[gi] = *reinterpret_cast<const uint4*>(img + (uint32_t)(yc * W) + (uint32_t)xc);
+    }
+    // halo: wave 2 takes tile rows 0..31, wave 3 rows 32..37 (other waves load a harmless duplicate)
+    const int hr = (wave == 3 ? 32 : 0) + (lane >> 1);
+    const int hy = y0 - 3 + hr;
+    const int hyc = hy < 0 ? 0 : (hy < H ? hy : H - 1);
+    const int hx = (lane & 1) ? x0 + 256 : x0 - 4;
+    const int hxc = hx < 0 ? 0 : (hx < W ? hx : W - 4);
+    st.h = *reinterpret_cast<const uint32_t*>(img + (uint32_t)(hyc * W) + (uint32_t)hxc);
+}
+
+__device__ __forceinline__ void fast_stage16_store(const FastStage16& st, uint32_t* tile32, int H, int W,
+                                                   int x0, int y0, int lane, int wave)
+{
+    const int x = x0 + 16 * (lane & 15);
+    const bool colok = x < W;
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+        const int r = 4 * (wave + 4 * gi) + (lane >> 4), y = y0 - 3 + r;
+        if (r < FT_LH) {
+            const bool ok = colok && y >= 0 && y < H;
+            uint4 v = st.v[gi];
+            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(tile32 + r * FT_PITCH + FT_X0 + 4 * (lane & 15)) = v;
+        }
+    }
+    if (wave >= 2) {
+        const int hr = (wave == 3 ? 32 : 0) + (lane >> 1);
+        const int hy = y0 - 3 + hr;
+        const int hx = (lane & 1) ? x0 + 256 : x0 - 4;
+        if (hr < FT_LH && (wave == 2 || lane < 12)) {
+            const bool ok = hy >= 0 && hy < H && hx >= 0 && hx < W;
+            tile32[hr * FT_PITCH + ((lane & 1) ? FT_X0 + 64 : FT_X0 - 1)] = ok ? st.h : 0u;
+        }
+    }
 }
 
 // Staging for images whose rows are not whole aligned dwords: bytes assembled one by one.
@@ -365,7 +424,7 @@ __device__ __forceinline__ void fast_stage_bytes(uint32_t* tile32, const uint8_t
         const int y = y0 - 3 + r;
         const bool rowok = y >= 0 && y < H;
         const uint8_t* row = img + (size_t)(rowok ? y : 0) * W;
-        for (int j = lane; j < FT_PITCH; j += 64) {
+        for (int j = lane; j < FT_W / 4 + 2; j += 64) {
             const int x = x0 - 4 + 4 * j;
             uint32_t v = 0;
             if (rowok) {
@@ -375,7 +434,7 @@ __device__ __forceinline__ void fast_stage_bytes(uint32_t* tile32, const uint8_t
                     if (xx >= 0 && xx < W) v |= (uint32_t)row[xx] << (8 * b);
                 }
             }
-            tile32[r * FT_PITCH + j] = v;
+            tile32[r * FT_PITCH + FT_X0 - 1 + j] = v;
         }
     }
 }
@@ -393,12 +452,12 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
         // rw[i] = dword of tile row r0 + i at this lane's column (output row rr uses rw[rr .. rr + 6])
         uint32_t rw[FT_ROWS_PER_WAVE + 6];
 #pragma unroll
-        for (int i = 0; i < FT_ROWS_PER_WAVE + 6; ++i) rw[i] = tile32[(r0 + i) * FT_PITCH + lane + 1];
+        for (int i = 0; i < FT_ROWS_PER_WAVE + 6; ++i) rw[i] = tile32[(r0 + i) * FT_PITCH + FT_X0 + lane];
 #pragma unroll
         for (int rr = 0; rr < FT_ROWS_PER_WAVE; ++rr) {
             const uint32_t C = rw[rr + 3], N = rw[rr], S = rw[rr + 6];
-            const uint32_t Cp = tile32[(r0 + rr + 3) * FT_PITCH + lane];
-            const uint32_t Cn = tile32[(r0 + rr + 3) * FT_PITCH + lane + 2];
+            const uint32_t Cp = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 - 1 + lane];
+            const uint32_t Cn = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 + 1 + lane];
             const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3);    // pixels x+3 .. x+6
             const uint32_t Wd = __builtin_amdgcn_alignbyte(C, Cp, 1);   // pixels x-3 .. x
             const uint32_t sn = __builtin_amdgcn_sad_u8(N, C, 0u), ss = __builtin_amdgcn_sad_u8(S, C, 0u);
@@ -415,7 +474,7 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
         const bool act = i < countA;
         const uint32_t e = act ? listA[i] : 0u;
         const int rr = (int)(e >> 6), dw = (int)(e & 63u);
-        const uint32_t* rc = tile32 + (r0 + rr + 3) * FT_PITCH + dw;   // -> the dword left of C
+        const uint32_t* rc = tile32 + (r0 + rr + 3) * FT_PITCH + FT_X0 - 1 + dw;   // -> the dword left of C
         const uint32_t Cp = rc[0], C = rc[1], Cn = rc[2];
         const uint32_t N = rc[1 - 3 * FT_PITCH], S = rc[1 + 3 * FT_PITCH];
         const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3);
@@ -443,9 +502,9 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
 // parallelism than the prefetch bought.)
 __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
                                                         int W, uint32_t* __restrict__ mask, int MW,
-                                                        int aligned4)
+                                                        int aligned)
 {
-    __shared__ uint32_t tile32[FT_LH * FT_PITCH];                 // 10032 B
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH + 4];             // 10352 B (+ the last row's right halo)
     __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
     __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
     const int f = blockIdx.z;
@@ -454,7 +513,11 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
     const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
     const int lane = lane_id(), wave = wave_id();
 
-    if (aligned4) {
+    if (aligned == 16) {
+        FastStage16 st;
+        fast_stage16_load(st, img, H, W, x0, y0, lane, wave);
+        fast_stage16_store(st, tile32, H, W, x0, y0, lane, wave);
+    } else if (aligned == 4) {
         FastStage st;
         fast_stage_load(st, img, H, W, x0, y0, lane, wave);
         fast_stage_store(st, tile32, H, W, x0, y0, lane, wave);
@@ -477,8 +540,13 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
 {
     const int MW = mask_words(fs.W);
     dim3 grid((fs.W + FT_W - 1) / FT_W, (fs.H + FT_H - 1) / FT_H, fs.frames);
-    int aligned4 = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
-    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned4);
+    int aligned = 1;
+    if ((fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0) aligned = 16;
+    else if ((fs.W & 3) == 0 && ((uintptr_t)fs.gray & 3) == 0) aligned = 4;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ORBAMD_FAST_ALIGN"); force = e ? atoi(e) : 0; }
+    if (force && force < aligned) aligned = force;
+    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned);
 }
 
 // ---------------------------------------------------------------------------------------------
