@@ -29,6 +29,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 # Integer VALU peak: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s (the figure
 # behind the 157.3 TFLOP/s FP32 vector peak, which counts an FMA as two operations).
 INT_VALU_PEAK_TOPS = 78.6
+# What the matcher's own instruction mix (v_xor_b32 + v_bcnt_u32_b32, 1:1) sustains in a register-only
+# loop on MI355X (visual_slam_amd/csrc/micro/valu_peak.hip): v_bcnt_u32_b32 issues at half rate.
+INT_VALU_MEASURED_MIX_TOPS = 49.2
 
 
 def parse_args():
@@ -143,7 +146,8 @@ def main():
             ach = work / avg_s / 1e12
             rooflines[name] = {"bound": "int_valu", "achieved": ach, "peak": INT_VALU_PEAK_TOPS,
                                "unit": "Tintop/s", "frac": ach / INT_VALU_PEAK_TOPS, "traffic": None,
-                               "avg_ms": ms / launches}
+                               "avg_ms": ms / launches, "peak_measured_mix": INT_VALU_MEASURED_MIX_TOPS,
+                               "frac_of_measured_mix": ach / INT_VALU_MEASURED_MIX_TOPS}
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
 
     # ---- CPU baseline + result check on a bounded sample (rank 0, N = 1) ------------------------

@@ -216,3 +216,43 @@ def test_device_libm_parity_gate_descriptors(gctx):
     assert np.array_equal(vidx, evidx)
     bad = int((desc != edesc).any(axis=1).sum())
     assert bad == 0, "%d of %d descriptors differ" % (bad, len(edesc))
+
+
+def test_large_launch_uses_64_keypoints_per_wave_and_matches_oracle():
+    """A batch big enough (frames x capacity >= 2^19) to take the 64-keypoints-per-wave variant of the
+    orientation / descriptor kernel; frames spot-checked against the oracle, all frames for counts."""
+    import torch
+    from visual_slam_amd.engine import OrbEngine
+    P = synth.PRESETS["480p"]
+    e = OrbEngine(0, cap=8192)
+    F = 64
+    gray = e.synth_frames(F, P["H"], P["W"], first_frame=500, cell=P["cell"], density=P["density"])
+    feat = e.extract_batch(gray)
+    m = e.match_consecutive(feat)
+    e.sync()
+    host = gray.cpu().numpy()
+    counts = feat.counts.cpu().numpy()
+    prev = None
+    for f in (0, 1, 31, 62, 63):
+        ekp, edesc, evidx = oracle.c.extract_gray(host[f])
+        kp, desc, vidx = feat.frame(f)
+        assert counts[f].tolist() == [len(ekp), len(edesc)]
+        assert np.array_equal(bits(kp), bits(ekp)) and np.array_equal(desc, edesc) and np.array_equal(vidx, evidx)
+        if prev is not None and prev[0] == f - 1:
+            eidx, edist = oracle.c.knn2(edesc, prev[1])
+            idx, dist, _ = m.pair(f - 1, len(edesc))
+            assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        prev = (f, edesc)
+
+
+def test_describe_with_non_finite_and_huge_angles(gctx):
+    """Caller-supplied angles that are NaN / infinite make every rotated coordinate NaN; the
+    reference's cvRound then returns INT_MIN, every sample is outside the image and reads 0, so the
+    descriptor is all zeros.  Huge finite angles go through the library's argument reduction."""
+    img = make_test_image(100, 140, 41)
+    xy = np.array([[50, 50], [60, 40], [70, 55], [40, 60], [90, 50], [30, 30]], np.int32)
+    ang = np.array([np.nan, np.inf, -np.inf, 1e30, -12345.678, 3.0e5], np.float32)
+    desc, vidx = gctx.describe(img, xy, ang)
+    edesc, evidx = oracle.c.describe(img, xy, ang)
+    assert np.array_equal(vidx, evidx) and np.array_equal(desc, edesc)
+    assert not desc[:3].any()

@@ -144,3 +144,11 @@ def test_ratio_filter_matches_oracle(gctx):
     assert gq.tolist() == [1] and g2.tolist() == [3] and g1.tolist() == [2]
     with pytest.raises(ValueError):
         gctx.ratio_filter(np.array([[0, -1]], np.int32), np.array([[5, -1]], np.int32))
+
+
+@pytest.mark.parametrize("H,W", [(67, 1000), (50, 530), (40, 259), (64, 272), (35, 4099)])
+def test_extract_on_widths_that_exercise_every_staging_path(gctx, H, W):
+    """W % 16 == 0 takes 16-byte staging loads, W % 4 == 0 dword loads, anything else the byte path;
+    widths around the 256-pixel tile edge and wider than one wave's 64 mask words are included."""
+    img = make_test_image(H, W, 1000 + W)
+    assert_extract_equal(gctx.extract_gray(img), oracle.c.extract_gray(img))

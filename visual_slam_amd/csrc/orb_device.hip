@@ -543,9 +543,6 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
     int aligned = 1;
     if ((fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0) aligned = 16;
     else if ((fs.W & 3) == 0 && ((uintptr_t)fs.gray & 3) == 0) aligned = 4;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ORBAMD_FAST_ALIGN"); force = e ? atoi(e) : 0; }
-    if (force && force < aligned) aligned = force;
     hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned);
 }
 
