@@ -148,6 +148,18 @@ def main():
                                "unit": "Tintop/s", "frac": ach / INT_VALU_PEAK_TOPS, "traffic": None,
                                "avg_ms": ms / launches, "peak_measured_mix": INT_VALU_MEASURED_MIX_TOPS,
                                "frac_of_measured_mix": ach / INT_VALU_MEASURED_MIX_TOPS}
+    # HBM traffic per launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE and WRITE_SIZE
+    # collected separately, FETCH_SIZE doubled where the kernel streams with 16-byte loads, as the
+    # gfx950 notes prescribe); produced by scripts/collect_traffic.py, valid for the default workload.
+    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                "r01_pmc_traffic_1080p_1000frames.json")
+    if args.preset == "1080p" and F == 1000 and os.path.exists(traffic_file):
+        pmc = json.load(open(traffic_file))
+        for name, key in (("fast_mask", "fast_mask_kernel"), ("rowcount", "rowcount_kernel"),
+                          ("rowscan", "rowscan_kernel"), ("emit", "emit_kernel"),
+                          ("orient_describe", "orient_describe_kernel"), ("knn2", "knn2_kernel")):
+            if name in rooflines and key in pmc:
+                rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
 
     # ---- CPU baseline + result check on a bounded sample (rank 0, N = 1) ------------------------

@@ -502,15 +502,23 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
 // parallelism than the prefetch bought.)
 __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
                                                         int W, uint32_t* __restrict__ mask, int MW,
-                                                        int aligned)
+                                                        int aligned, int ntc, int ntr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH + 4];             // 10352 B (+ the last row's right halo)
     __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
     __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
-    const int f = blockIdx.z;
+    // 1-D grid, tile column fastest.  Neighbouring tiles read each other's edge cache lines (the
+    // halo), so a tile's neighbours should run on the SAME XCD and find those lines in its L2: with
+    // the plain mapping and 8 tile columns every column would be pinned to its own XCD and each tile
+    // row would pull two extra lines through the fabric.
+    const uint32_t item = xcd_contiguous_item();
+    const int bx = (int)(item % (uint32_t)ntc);
+    const uint32_t rest = item / (uint32_t)ntc;
+    const int by = (int)(rest % (uint32_t)ntr);
+    const int f = (int)(rest / (uint32_t)ntr);
     const uint8_t* img = gray + (size_t)f * H * W;
     uint32_t* mfr = mask + (size_t)f * H * MW;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = bx * FT_W, y0 = by * FT_H;
     const int lane = lane_id(), wave = wave_id();
 
     if (aligned == 16) {
@@ -539,11 +547,12 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
 void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
 {
     const int MW = mask_words(fs.W);
-    dim3 grid((fs.W + FT_W - 1) / FT_W, (fs.H + FT_H - 1) / FT_H, fs.frames);
+    const int ntc = (fs.W + FT_W - 1) / FT_W, ntr = (fs.H + FT_H - 1) / FT_H;
+    dim3 grid((unsigned)((size_t)ntc * ntr * fs.frames));
     int aligned = 1;
     if ((fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0) aligned = 16;
     else if ((fs.W & 3) == 0 && ((uintptr_t)fs.gray & 3) == 0) aligned = 4;
-    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned);
+    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned, ntc, ntr);
 }
 
 // ---------------------------------------------------------------------------------------------
