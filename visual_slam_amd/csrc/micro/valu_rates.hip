@@ -124,6 +124,31 @@ __global__ __launch_bounds__(256) void k_cvt_f64_i32(uint32_t* out, int iters, u
     out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s;
 }
 
+
+// One operand in a scalar register (wave-uniform), as the Hamming kernel's train row is.
+#define DEFKERNEL_S(NAME, ASM)                                                            \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t* out, int iters, uint32_t seed) \
+    {                                                                                     \
+        uint32_t a[8];                                                                    \
+        for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 0x9E3779B9u;    \
+        uint32_t t = __builtin_amdgcn_readfirstlane(seed ^ blockIdx.x);                   \
+        for (int it = 0; it < iters; ++it) {                                              \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
+                _Pragma("unroll") for (int w = 0; w < 8; ++w)                             \
+                    asm volatile(ASM : "+v"(a[w]) : "s"(t));                              \
+            }                                                                             \
+        }                                                                                 \
+        uint32_t s = 0;                                                                   \
+        for (int i = 0; i < 8; ++i) s += a[i];                                            \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                          \
+    }
+DEFKERNEL_S(xor_sgpr, "v_xor_b32_e32 %0, %1, %0")
+DEFKERNEL_S(add_sgpr, "v_add_u32_e32 %0, %1, %0")
+DEFKERNEL_S(mov_sgpr, "v_mov_b32_e32 %0, %1")
+DEFKERNEL_S(xor_lit, "v_xor_b32_e32 %0, 0x12345678, %0")
+DEFKERNEL_S(xor_inl, "v_xor_b32_e32 %0, 17, %0")
+DEFKERNEL_S(bcnt_sgpr, "v_bcnt_u32_b32 %0, %1, %0")
+
 typedef void (*kern_t)(uint32_t*, int, uint32_t);
 
 int run(const char* name, kern_t k, int ops_per_stmt, uint32_t* d)
@@ -164,5 +189,6 @@ int main()
     RUN(mul_lo_u32, 1) RUN(add_f32, 1) RUN(mul_f32, 1) RUN(rndne_f32, 1) RUN(cvt_i32_f32, 1) RUN(cvt_f32_i32, 1)
     RUN(lshl_add, 1) RUN(add_lshl, 1) RUN(mul_f64, 1) RUN(add_f64, 1) RUN(fma_f64, 1)
     RUN(cvt_f32_f64, 1) RUN(cvt_f64_i32, 1)
+    RUN(xor_sgpr, 1) RUN(add_sgpr, 1) RUN(mov_sgpr, 1) RUN(xor_lit, 1) RUN(xor_inl, 1) RUN(bcnt_sgpr, 1)
     return 0;
 }

@@ -1135,13 +1135,40 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
     uint32_t m1[QPL], m2[QPL];
 #pragma unroll
     for (int u = 0; u < QPL; ++u) { m1[u] = KEY_NONE; m2[u] = KEY_NONE; }
+    // A row can only change a lane's top-2 if its distance is below that lane's second-best
+    // distance (an equal distance carries a larger train index, so its key is larger).  After the
+    // first few hundred rows that is rare, so each trip tests min(distances) < second-best once
+    // and skips the key build and the three-way inserts when no lane needs them.  The bound is
+    // refreshed only inside the slow path; a stale (larger) bound merely takes that path, where
+    // inserting a key that is not below m2 leaves (m1, m2) unchanged.
+    uint32_t bound[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; ++u) bound[u] = KEY_NONE >> 18;
+
     int j = t0;
     for (; j + RPT <= t1; j += RPT, tp += 8 * RPT) {
+        uint32_t d[RPT][QPL];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
 #pragma unroll
-            for (int u = 0; u < QPL; ++u)
-                top2_insert(m1[u], m2[u], (hamming256(q[u], tp + 8 * r) << 18) | (uint32_t)(j + r));
+            for (int u = 0; u < QPL; ++u) d[r][u] = hamming256(q[u], tp + 8 * r);
+        }
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < QPL; ++u) {
+            uint32_t mn = d[0][u];
+#pragma unroll
+            for (int r = 1; r < RPT; ++r) mn = mn < d[r][u] ? mn : d[r][u];
+            any |= mn < bound[u];
+        }
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    top2_insert(m1[u], m2[u], (d[r][u] << 18) | (uint32_t)(j + r));
+                bound[u] = m2[u] >> 18;
+            }
         }
     }
     for (; j < t1; ++j, tp += 8) {
