@@ -61,6 +61,15 @@ int orbamd_ctx_set_stream(orbamd_ctx* ctx, void* hip_stream);
 int orbamd_ctx_sync(orbamd_ctx* ctx);
 /* Text of the last HIP failure seen by this context ("" if none). */
 const char* orbamd_last_error(orbamd_ctx* ctx);
+/* Which kernel family computes the Hamming top-2 (all orbamd_knn2* calls of this context).  Both
+ * give the results of cv2.BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) (reference views.py:65, :162)
+ * bit for bit.  MATRIX (default): descriptors as +-1 FP4 values on the matrix cores, distance =
+ * (256 - dot) / 2, exact.  VALU: XOR + popcount on the vector ALUs.  The default can also be
+ * chosen with the environment variable ORBAMD_MATCHER=valu|matrix read at context creation.
+ * No counterpart in the reference. */
+#define ORBAMD_MATCHER_MATRIX 0
+#define ORBAMD_MATCHER_VALU   1
+int orbamd_ctx_set_matcher(orbamd_ctx* ctx, int matcher);
 
 /* Per-kernel timing: when enabled, every kernel launch is bracketed by HIP events on the
  * context's stream.  orbamd_ctx_timing_read() drains the stream and returns, for kernel kind k
@@ -75,7 +84,8 @@ const char* orbamd_last_error(orbamd_ctx* ctx);
 #define ORBAMD_K_KNN2_MERGE 7
 #define ORBAMD_K_SYNTH      8
 #define ORBAMD_K_RATIO      9
-#define ORBAMD_K_COUNT      10
+#define ORBAMD_K_KNN2_EXPAND 10
+#define ORBAMD_K_COUNT      11
 int orbamd_ctx_timing_enable(orbamd_ctx* ctx, int on);
 int orbamd_ctx_timing_reset(orbamd_ctx* ctx);
 int orbamd_ctx_timing_read(orbamd_ctx* ctx, double ms_out[ORBAMD_K_COUNT], long launches_out[ORBAMD_K_COUNT]);

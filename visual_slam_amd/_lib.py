@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "liborbamd.so")
 
 OK, E_BADARG, E_CAPACITY, E_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 MAX_TRAIN = 1 << 18
-K_COUNT = 10
+K_COUNT = 11
+MATCHER_MATRIX, MATCHER_VALU = 0, 1
 
 _c_ctx = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -32,6 +33,7 @@ SIGNATURES = {
     "orbamd_ctx_set_stream": (_int, [_c_ctx, _vp]),
     "orbamd_ctx_sync": (_int, [_c_ctx]),
     "orbamd_last_error": (ctypes.c_char_p, [_c_ctx]),
+    "orbamd_ctx_set_matcher": (_int, [_c_ctx, _int]),
     "orbamd_ctx_timing_enable": (_int, [_c_ctx, _int]),
     "orbamd_ctx_timing_reset": (_int, [_c_ctx]),
     "orbamd_ctx_timing_read": (_int, [_c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
@@ -149,6 +151,10 @@ class Context:
 
     def sync(self):
         self._chk(lib().orbamd_ctx_sync(self._h), "sync")
+
+    def set_matcher(self, matcher):
+        """MATCHER_MATRIX (default) or MATCHER_VALU: the kernel family used by every knn2 call."""
+        self._chk(lib().orbamd_ctx_set_matcher(self._h, int(matcher)), "set_matcher")
 
     def timing_enable(self, on=True):
         self._chk(lib().orbamd_ctx_timing_enable(self._h, 1 if on else 0), "timing_enable")

@@ -1,6 +1,7 @@
 // orb_capi.hip -- the extern "C" surface of liborbamd.so (declared in include/orbamd.h): context,
 // grow-only device work buffers, host<->device staging and kernel sequencing.  No computation on
 // image or descriptor data happens on the host in this file.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -34,7 +35,8 @@ struct orbamd_ctx {
 
     // work buffers
     DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle;
-    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
+    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount, xq, xt;
+    int matcher = ORBAMD_MATCHER_MATRIX;
     int32_t* h_counts = nullptr;  // pinned, 4 ints
 
     // state of the last single-frame extract
@@ -204,12 +206,13 @@ int read_counts(orbamd_ctx* c, const int32_t* d_counts, int nints)
     return ORBAMD_OK;
 }
 
-int choose_splits(int nq, int nt, int npairs)
+// Train-axis splits so that small jobs still fill the chip: aim for >= `target` workgroups of
+// `rows_per_block` queries, keep every train chunk >= 256 rows.
+int choose_splits(int nq, int nt, int npairs, int rows_per_block, int target)
 {
-    // Aim for >= ~2048 workgroups in flight; keep every train chunk >= 256 rows.
-    long blocks = (long)((nq + 255) / 256) * npairs;
+    long blocks = (long)((nq + rows_per_block - 1) / rows_per_block) * npairs;
     if (blocks <= 0) return 1;
-    long s = (2048 + blocks - 1) / blocks;
+    long s = (target + blocks - 1) / blocks;
     long smax = nt / 256;
     if (s > smax) s = smax;
     if (s > 64) s = 64;
@@ -217,17 +220,55 @@ int choose_splits(int nq, int nt, int npairs)
     return (int)s;
 }
 
+size_t fp4_image_bytes(int rows) { return (size_t)((rows + 31) / 32) * 4096; }
+
 int run_knn2(orbamd_ctx* c, Knn2Args& a)
 {
+    const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
+    const int ntmax = a.tcounts ? a.cap : a.nt_fixed;
+    const bool matrix = c->matcher == ORBAMD_MATCHER_MATRIX;
+    a.splits = matrix ? choose_splits(nqmax, ntmax, a.npairs, 256, 1024)
+                      : choose_splits(nqmax, ntmax, a.npairs, 256, 2048);
     if (a.splits > 1) {
         CHK(ensure(c, c->partial, (size_t)a.npairs * a.splits * a.cap * 2 * sizeof(uint32_t)));
         a.partial = (uint32_t*)c->partial.p;
     }
+    if (matrix) {
+        a.xq_stride = fp4_image_bytes(nqmax);
+        a.xt_stride = fp4_image_bytes(ntmax);
+        const bool one_batch = !a.pairs && a.qcounts && a.qdesc == a.tdesc && a.qcounts == a.tcounts &&
+                               a.qframe0 == a.tframe0;
+        if (one_batch) {
+            CHK(ensure(c, c->xq, (size_t)(a.npairs + 1) * a.xq_stride));
+        } else {
+            CHK(ensure(c, c->xq, (size_t)a.npairs * a.xq_stride));
+            CHK(ensure(c, c->xt, (size_t)a.npairs * a.xt_stride));
+        }
+        Timed t(c, ORBAMD_K_KNN2_EXPAND);
+        if (one_batch) {
+            // consecutive pairs of one batch: every frame is expanded once and used on both sides
+            launch_expand_fp4(a.qdesc, a.qcounts, nullptr, 0, a.tframe0, a.npairs + 1, a.cap, 0,
+                              (uint8_t*)c->xq.p, a.xq_stride, c->stream);
+            a.xq = a.xt = (const uint8_t*)c->xq.p;
+            a.qslot0 = 1;
+            a.tslot0 = 0;
+        } else {
+            launch_expand_fp4(a.qdesc, a.qcounts, a.pairs, 0, a.qframe0 + 1, a.npairs, a.cap, a.nq_fixed,
+                              (uint8_t*)c->xq.p, a.xq_stride, c->stream);
+            launch_expand_fp4(a.tdesc, a.tcounts, a.pairs, 1, a.tframe0, a.npairs, a.cap, a.nt_fixed,
+                              (uint8_t*)c->xt.p, a.xt_stride, c->stream);
+            a.xq = (const uint8_t*)c->xq.p;
+            a.xt = (const uint8_t*)c->xt.p;
+            a.qslot0 = a.tslot0 = 0;
+        }
+    }
+    if (matrix) CHK(post_launch(c, "expand_fp4_kernel"));
     {
         Timed t(c, ORBAMD_K_KNN2);
-        launch_knn2(a, c->stream);
+        if (matrix) launch_knn2_mfma(a, c->stream);
+        else launch_knn2(a, c->stream);
     }
-    CHK(post_launch(c, "knn2_kernel"));
+    CHK(post_launch(c, matrix ? "knn2_mfma_kernel" : "knn2_kernel"));
     if (a.splits > 1) {
         {
             Timed t(c, ORBAMD_K_KNN2_MERGE);
@@ -292,7 +333,8 @@ const char* orbamd_status_string(int status)
 const char* orbamd_kernel_name(int kind)
 {
     static const char* names[ORBAMD_K_COUNT] = {"bgr2gray", "fast_mask", "rowcount", "rowscan", "emit",
-                                                "orient_describe", "knn2", "knn2_merge", "synth", "ratio_compact"};
+                                                "orient_describe", "knn2", "knn2_merge", "synth", "ratio_compact",
+                                                "knn2_expand"};
     return (kind >= 0 && kind < ORBAMD_K_COUNT) ? names[kind] : "?";
 }
 
@@ -314,7 +356,16 @@ int orbamd_ctx_create(int device, orbamd_ctx** out)
         return ORBAMD_E_DEVICE;
     }
     c->stream = c->own_stream;
+    if (const char* e = getenv("ORBAMD_MATCHER"))
+        if (strcmp(e, "valu") == 0) c->matcher = ORBAMD_MATCHER_VALU;
     *out = c;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_set_matcher(orbamd_ctx* c, int matcher)
+{
+    if (!c || (matcher != ORBAMD_MATCHER_MATRIX && matcher != ORBAMD_MATCHER_VALU)) return ORBAMD_E_BADARG;
+    c->matcher = matcher;
     return ORBAMD_OK;
 }
 
@@ -324,7 +375,7 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
-                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->idx, &c->dist, &c->good,
+                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->xq, &c->xt, &c->idx, &c->dist, &c->good,
                       &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -563,7 +614,6 @@ int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     a.cap = nq;
     a.nq_fixed = nq;
     a.nt_fixed = nt;
-    a.splits = choose_splits(nq, nt, 1);
     a.idx = (int32_t*)c->idx.p;
     a.dist = (int32_t*)c->dist.p;
     CHK(run_knn2(c, a));
@@ -672,7 +722,6 @@ int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d
     a.pairs = d_pairs;
     a.npairs = npairs;
     a.cap = cap;
-    a.splits = choose_splits(cap, cap, npairs);
     a.idx = d_idx;
     a.dist = d_dist;
     a.good = d_good;
@@ -696,7 +745,6 @@ int orbamd_knn2_cross_dev(orbamd_ctx* c, const uint8_t* d_qdesc, const int32_t* 
     a.tframe0 = tframe;
     a.npairs = 1;
     a.cap = cap;
-    a.splits = choose_splits(cap, cap, 1);
     a.idx = d_idx;
     a.dist = d_dist;
     a.good = d_good;
@@ -717,7 +765,6 @@ int orbamd_knn2_dev(orbamd_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_
     a.cap = nq;
     a.nq_fixed = nq;
     a.nt_fixed = nt;
-    a.splits = choose_splits(nq, nt, 1);
     a.idx = d_idx;
     a.dist = d_dist;
     a.good = d_good;

@@ -1190,6 +1190,217 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hamming top-2 on the matrix cores.
+//
+// With every descriptor bit b stored as the FP4 (E2M1) value 1 - 2b, the dot product of two
+// 256-element rows is 256 - 2 * hamming(q, t): sums of +-1 products, exact in the f32 accumulator.
+// v_mfma_scale_f32_32x32x64_f8f6f4 (both operands FP4, both scales 2^0) multiplies a 32-row train
+// tile by a 32-column query tile over 64 bits per instruction, four instructions per tile.
+//
+// The accumulator comes out with the column (query) on the lane and 16 train rows in the 16
+// registers of a lane (row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  Starting the
+// accumulator at -256 - row / 4096 makes each register -(2 * distance + row / 4096): a complete
+// (distance, train index) key as one exact float (10 integer bits + 12 fraction bits), larger =
+// better, so the running top-2 of a lane is one v_med3_f32 and one v_max_f32 per element and no
+// key has to be built.  After every tile the two running keys are raised by 32 / 4096, which
+// makes their index fields relative to the start of the next tile (negative for rows already
+// seen); the fields stay inside the distance step of 2 for 8192 rows, after which (and at the
+// end) the keys are decoded into the integer (distance << 18) | index form and merged there.
+// Lanes l and l + 32 hold disjoint train rows of the same query and are merged at the end.
+//
+// Operand image ("FP4 image") of one descriptor set: tiles of 32 rows, 4096 bytes per tile laid
+// out as [piece 0..7][row 0..31][16 bytes]; piece p holds descriptor dword p as 32 nibbles, dword s
+// of the piece taking bits s, s + 4, ..., s + 28.  A lane's operand for k-step ks is the 16 bytes
+// at tile + ks * 1024 + lane * 16, so fragments are read with lane-linear 16-byte accesses both
+// from global memory and from LDS.  The bit-to-k assignment is the same for both operands, which
+// is all a dot product needs.
+// ---------------------------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void expand_fp4_kernel(const uint8_t* __restrict__ desc,
+                                                         const int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ pairs, int side,
+                                                         int frame0, int cap, int n_fixed,
+                                                         uint8_t* __restrict__ x, size_t xstride)
+{
+    const int slot = blockIdx.y, tile = blockIdx.x;
+    int f = 0, n = n_fixed;
+    if (counts) {
+        f = pairs ? pairs[2 * slot + side] : frame0 + slot;
+        n = counts[2 * f + 1];
+        n = n < cap ? n : cap;
+    }
+    if (tile * 32 >= n) return;
+    const int p = threadIdx.x >> 5, r = threadIdx.x & 31;
+    const int row = tile * 32 + r;
+    uint32_t w = 0;
+    if (row < n) w = reinterpret_cast<const uint32_t*>(desc + ((size_t)f * cap + row) * 32)[p];
+    uint4 o;
+    o.x = ((w << 3) & 0x88888888u) | 0x22222222u;   // nibble = sign bit | 0b010 (magnitude 1.0)
+    o.y = ((w << 2) & 0x88888888u) | 0x22222222u;
+    o.z = ((w << 1) & 0x88888888u) | 0x22222222u;
+    o.w = (w & 0x88888888u) | 0x22222222u;
+    reinterpret_cast<uint4*>(x + (size_t)slot * xstride + (size_t)tile * 4096)[threadIdx.x] = o;
+}
+
+__device__ __forceinline__ void top2_insert_f32(float& m1, float& m2, float key)
+{
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m1), "v"(m2), "v"(key));
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(key));
+}
+
+// Float key after `tiles` tiles of a run that started at train row row0 -> integer key.
+__device__ __forceinline__ uint32_t knn2_decode_key(float f, int tiles, int row0)
+{
+    if (f == -INFINITY) return KEY_NONE;
+    const int w = (int)(f * -4096.0f) + 8192;       // 8192 * distance + (index - 32 * tiles + 8192)
+    const int d = w >> 13;
+    const int i = (w & 8191) - 8192 + 32 * tiles + row0;
+    return ((uint32_t)d << 18) | (uint32_t)i;
+}
+
+constexpr int KNN2_RUN_TILES = 256;   // 8192 rows: the index field of a float key must stay below 2.0
+
+// QT query tiles (32 queries each) per wave, 4 waves per workgroup; the train tiles stream
+// through a double-buffered 4 KiB LDS tile shared by the 4 waves.
+template <int QT, bool PARTIAL>
+__global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restrict__ xq,
+                                                        const uint8_t* __restrict__ xt, size_t xq_stride,
+                                                        size_t xt_stride, int qslot0, int tslot0,
+                                                        const int32_t* __restrict__ qcounts,
+                                                        const int32_t* __restrict__ tcounts,
+                                                        const int32_t* __restrict__ pairs, int qframe0,
+                                                        int tframe0, int cap, int nq_fixed, int nt_fixed,
+                                                        int splits, int nbp, uint32_t* __restrict__ partial,
+                                                        int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                        uint8_t* __restrict__ good)
+{
+    __shared__ uint4 stage[2][256];
+
+    int pair, zsplit, qblk;
+    {
+        const uint32_t logical = xcd_contiguous_item();
+        const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
+        pair = (int)(logical / per_pair);
+        const uint32_t rem = logical - (uint32_t)pair * per_pair;
+        zsplit = (int)(rem / (uint32_t)nbp);
+        qblk = (int)(rem - (uint32_t)zsplit * (uint32_t)nbp);
+    }
+    int nq = nq_fixed, nt = nt_fixed;
+    if (qcounts) {
+        int qf, tf;
+        if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
+        else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
+        nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+        nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
+    }
+    if (qblk * (128 * QT) >= nq) return;              // uniform over the workgroup
+
+    const int lane = lane_id(), wave = wave_id();
+    const int h = lane >> 5;
+    const int qtile0 = (qblk * 4 + wave) * QT;
+    const bool wave_has_queries = qtile0 * 32 < nq;   // waves without queries only help staging
+
+    const uint8_t* xqf = xq + (size_t)(pair + qslot0) * xq_stride;
+    const uint8_t* xtf = xt + (size_t)(pair + tslot0) * xt_stride;
+
+    v8i b[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((qtile0 + u) * 32 < nq)
+                v = reinterpret_cast<const uint4*>(xqf + (size_t)(qtile0 + u) * 4096 + ks * 1024)[lane];
+            b[u][ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+        }
+    }
+
+    v16f cin;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        cin[i] = -256.0f - (float)((i & 3) + 8 * (i >> 2) + 4 * h) * (1.0f / 4096.0f);
+
+    const int tiles_total = (nt + 31) >> 5;
+    const int tiles_per_split = (tiles_total + splits - 1) / splits;
+    const int tbeg = zsplit * tiles_per_split;
+    int tend = tbeg + tiles_per_split; tend = tend < tiles_total ? tend : tiles_total;
+
+    uint32_t k1[QT], k2[QT];
+    float m1[QT], m2[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { k1[u] = KEY_NONE; k2[u] = KEY_NONE; m1[u] = -INFINITY; m2[u] = -INFINITY; }
+
+    const int scale_one = 0x7F;   // E8M0 exponent 127 = 2^0
+    const uint4* __restrict__ tsrc = reinterpret_cast<const uint4*>(xtf) + (size_t)tbeg * 256 + threadIdx.x;
+    uint4 next = make_uint4(0, 0, 0, 0);
+    if (tbeg < tend) next = tsrc[0];
+    int run_row0 = tbeg * 32, run_tiles = 0;
+    for (int t = tbeg; t < tend; ++t) {
+        const int buf = (t - tbeg) & 1;
+        stage[buf][threadIdx.x] = next;
+        __syncthreads();
+        if (t + 1 < tend) next = tsrc[(size_t)(t + 1 - tbeg) * 256];
+        if (wave_has_queries) {
+            v8i a[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 v = stage[buf][ks * 64 + lane];
+                a[ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+            }
+            v16f c0 = cin;
+            if ((t + 1) * 32 > nt) {                  // last, partial tile: rows past nt never win
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) top2_insert_f32(m1[u], m2[u], acc[i]);
+                m1[u] += 32.0f / 4096.0f;
+                m2[u] += 32.0f / 4096.0f;
+            }
+            ++run_tiles;
+            if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    top2_insert(k1[u], k2[u], knn2_decode_key(m1[u], run_tiles, run_row0));
+                    top2_insert(k1[u], k2[u], knn2_decode_key(m2[u], run_tiles, run_row0));
+                    m1[u] = -INFINITY;
+                    m2[u] = -INFINITY;
+                }
+                run_row0 += run_tiles * 32;
+                run_tiles = 0;
+            }
+        }
+    }
+
+    if (!wave_has_queries) return;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const uint32_t p1 = (uint32_t)__shfl_xor((int)k1[u], 32);
+        const uint32_t p2 = (uint32_t)__shfl_xor((int)k2[u], 32);
+        top2_insert(k1[u], k2[u], p1);
+        top2_insert(k1[u], k2[u], p2);
+        const int qi = (qtile0 + u) * 32 + (lane & 31);
+        if (h == 0 && qi < nq) {
+            if (PARTIAL) {
+                const size_t o = (((size_t)pair * splits + zsplit) * cap + qi);
+                reinterpret_cast<uint2*>(partial)[o] = make_uint2(k1[u], k2[u]);
+            } else {
+                knn2_store(k1[u], k2[u], idx, dist, good, (size_t)pair * cap + qi);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ qcounts,
                                                          const int32_t* __restrict__ pairs, int qframe0,
                                                          int cap, int nq_fixed, int splits,
@@ -1288,6 +1499,32 @@ void launch_knn2(const Knn2Args& a, hipStream_t s)
     // train rows per trip and single-wave workgroups was the fastest of the tilings tried
     // (more queries per lane or 256-thread workgroups were 1-40 % slower).
     launch_knn2_variant<1, 4, 64>(a, s);
+}
+
+void launch_expand_fp4(const uint8_t* desc, const int32_t* counts, const int32_t* pairs, int side, int frame0,
+                       int nslots, int cap, int n_fixed, uint8_t* x, size_t xstride, hipStream_t s)
+{
+    const int nmax = counts ? cap : n_fixed;
+    if (nslots <= 0 || nmax <= 0) return;
+    dim3 grid((nmax + 31) / 32, nslots);
+    hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, s, desc, counts, pairs, side, frame0, cap, n_fixed,
+                       x, xstride);
+}
+
+void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
+{
+    constexpr int QT = 2;
+    const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
+    const int nbp = ((nqmax + 128 * QT - 1) / (128 * QT)) | 1;   // odd: see xcd_contiguous_item()
+    dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
+    if (a.splits > 1)
+        hipLaunchKernelGGL((knn2_mfma_kernel<QT, true>), grid, dim3(256), 0, s, a.xq, a.xt, a.xq_stride,
+                           a.xt_stride, a.qslot0, a.tslot0, a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
+    else
+        hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), 0, s, a.xq, a.xt, a.xq_stride,
+                           a.xt_stride, a.qslot0, a.tslot0, a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+                           a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
 }
 
 void launch_knn2_merge(const Knn2Args& a, hipStream_t s)
