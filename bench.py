@@ -32,6 +32,9 @@ INT_VALU_PEAK_TOPS = 78.6
 # What the matcher's own instruction mix (v_xor_b32 + v_bcnt_u32_b32, 1:1) sustains in a register-only
 # loop on MI355X (visual_slam_amd/csrc/micro/valu_peak.hip): v_bcnt_u32_b32 issues at half rate.
 INT_VALU_MEASURED_MIX_TOPS = 49.2
+# Dense FP4 matrix-core peak (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4): 256 CUs x 4 SIMDs
+# x 4096 FLOP/clk x 2.4 GHz.
+MFMA_FP4_PEAK_TFLOPS = 10066.0
 
 
 def parse_args():
@@ -44,6 +47,8 @@ def parse_args():
     ap.add_argument("--cap", type=int, default=0, help="keypoint capacity per frame (0 = by preset)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-kernel HIP events")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--matcher", default="matrix", choices=["matrix", "valu"],
+                    help="Hamming top-2 kernel family: matrix cores (default) or XOR/popcount on the vector ALUs")
     return ap.parse_args()
 
 
@@ -72,6 +77,8 @@ def main():
     cap = args.cap or {"480p": 4096, "1080p": 8192, "4k": 32768}[args.preset]
     F = args.frames
     eng = OrbEngine(local_rank, cap=cap)
+    from visual_slam_amd import _lib
+    eng.ctx.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
     gray = eng.synth_frames(F, H, W, first_frame=rank * F, cell=P["cell"], density=P["density"])
     feat = eng.alloc_features(F)
     matches = eng.alloc_matches(F - 1)
@@ -129,9 +136,14 @@ def main():
         "rowscan": ("hbm", float(F * (16 * H + 8))),
         "emit": ("hbm", float(F * H * MW8 + 8 * n.sum())),
         "orient_describe": ("hbm", float(np.minimum(H * W, 1849 * n).sum() + (8 + 4 + 28) * n.sum() + 32 * nv.sum())),
-        # integer operations per launch: 8 XOR + 8 popcount-accumulate per descriptor pair
-        "knn2": ("int_valu", float(16 * (nv[1:] * nv[:-1]).sum())),
+        "knn2_expand": ("hbm", float((32 + 128) * nv.sum())),
     }
+    if args.matcher == "valu":
+        # integer operations per launch: 8 XOR + 8 popcount-accumulate per descriptor pair
+        alg["knn2"] = ("int_valu", float(16 * (nv[1:] * nv[:-1]).sum()))
+    else:
+        # FLOP per launch: a 256-element +-1 dot product (256 multiply-adds) per descriptor pair
+        alg["knn2"] = ("mfma", float(512 * (nv[1:] * nv[:-1]).sum()))
     rooflines = {}
     for name, (bound, work) in alg.items():
         ms, launches = timing.get(name, (0.0, 0))
@@ -142,6 +154,11 @@ def main():
             ach = work / avg_s / 1e9
             rooflines[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": ms / launches}
+        elif bound == "mfma":
+            ach = work / avg_s / 1e12
+            rooflines[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "avg_ms": ms / launches,
+                               "operands": "fp4 e2m1 (+-1.0, exact), f32 accumulate"}
         else:
             ach = work / avg_s / 1e12
             rooflines[name] = {"bound": "int_valu", "achieved": ach, "peak": INT_VALU_PEAK_TOPS,
@@ -157,7 +174,9 @@ def main():
         pmc = json.load(open(traffic_file))
         for name, key in (("fast_mask", "fast_mask_kernel"), ("rowcount", "rowcount_kernel"),
                           ("rowscan", "rowscan_kernel"), ("emit", "emit_kernel"),
-                          ("orient_describe", "orient_describe_kernel"), ("knn2", "knn2_kernel")):
+                          ("orient_describe", "orient_describe_kernel"),
+                          ("knn2_expand", "expand_fp4_kernel"),
+                          ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
             if name in rooflines and key in pmc:
                 rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
@@ -199,6 +218,7 @@ def main():
                                    "consecutive pair" % (W, H, F, int(round(n.mean()))),
                        "frames_per_gpu": F, "keypoints_per_frame": float(n.mean()),
                        "descriptors_per_frame": float(nv.mean()), "capacity_per_frame": cap,
+                       "matcher": args.matcher,
                        "parallelism": "contiguous frame ranges, %d rank(s), RCCL send/recv of the seam frame"
                                       % world},
             "roofline": rooflines.get(dominant),

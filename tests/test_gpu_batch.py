@@ -127,6 +127,40 @@ def test_dense_matching_stress_20k(eng):
     assert np.array_equal(good.cpu().numpy(), want)
 
 
+def test_long_train_set_without_train_split(eng):
+    """More than 8192 train rows handled by ONE workgroup column: with thousands of pairs in a launch
+    the train axis is not split, so the matrix-core kernel has to close a run of float keys and
+    start the next one.  The same pair is listed many times; every copy must equal the oracle."""
+    import torch
+    from visual_slam_amd import _lib
+    cap, nt, nq, npairs = 9504, 9500, 37, 2100
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    q[0] = t[8191]; t[8192] = t[8191]; t[9499] = t[8191]      # ties across the run boundary
+    q[1] = t[0]; t[8200] = t[0]
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=eng.device)
+    desc[0, :nt] = torch.from_numpy(t).to(eng.device)
+    desc[1, :nq] = torch.from_numpy(q).to(eng.device)
+    counts = torch.tensor([[nt, nt], [nq, nq]], dtype=torch.int32, device=eng.device)
+    pairs = torch.tensor([[1, 0]] * npairs, dtype=torch.int32, device=eng.device)
+    eidx, edist = oracle.c.knn2(q, t)
+    assert eidx[0].tolist() == [8191, 8192] and eidx[1].tolist() == [0, 8200]
+    from visual_slam_amd.engine import BatchFeatures
+    feat = BatchFeatures(kp7=None, desc=desc, valid_idx=None, counts=counts, cap=cap)
+    for m in (_lib.MATCHER_MATRIX, _lib.MATCHER_VALU):
+        eng.ctx.set_matcher(m)
+        try:
+            out = eng.match_pairs(feat, pairs)
+            eng.sync()
+        finally:
+            eng.ctx.set_matcher(_lib.MATCHER_MATRIX)
+        idx = out.idx[:, :nq].cpu().numpy()
+        dist = out.dist[:, :nq].cpu().numpy()
+        assert (idx == eidx[None]).all() and (dist == edist[None]).all()
+        del out
+
+
 def test_matching_properties_self_match(eng):
     """Size-independent properties: a set matched against itself finds itself at distance 0 (lowest
     index among exact duplicates), dist0 <= dist1, indices in range; repeated runs are identical."""

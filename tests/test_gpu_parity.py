@@ -102,8 +102,17 @@ def test_bgr2gray_and_extract_bgr(gctx):
 KNN_CASES = [(1, 1), (5, 2), (64, 0), (3, 1), (257, 300), (1000, 1537), (2062, 1895), (300, 5000)]
 
 
+@pytest.fixture(params=["matrix", "valu"])
+def matcher(request, gctx):
+    """Runs a test once per Hamming kernel family; restores the default afterwards."""
+    from visual_slam_amd import _lib
+    gctx.set_matcher(_lib.MATCHER_VALU if request.param == "valu" else _lib.MATCHER_MATRIX)
+    yield request.param
+    gctx.set_matcher(_lib.MATCHER_MATRIX)
+
+
 @pytest.mark.parametrize("nq,nt", KNN_CASES)
-def test_knn2_matches_oracle(gctx, nq, nt):
+def test_knn2_matches_oracle(gctx, matcher, nq, nt):
     q = synth.synth_descriptors(nq, 100 + nq, dup_frac=0.05)
     t = synth.synth_descriptors(nt, 200 + nt, dup_frac=0.05) if nt else np.zeros((0, 32), np.uint8)
     if nt >= 8:
@@ -116,7 +125,7 @@ def test_knn2_matches_oracle(gctx, nq, nt):
     assert np.array_equal(dist, edist)
 
 
-def test_knn2_low_entropy_ties(gctx):
+def test_knn2_low_entropy_ties(gctx, matcher):
     """Descriptors from a tiny alphabet: almost every distance is tied."""
     rng = np.random.default_rng(21)
     q = (rng.integers(0, 2, (700, 32)) * 255).astype(np.uint8)
@@ -124,6 +133,21 @@ def test_knn2_low_entropy_ties(gctx):
     idx, dist = gctx.knn2(q, t)
     eidx, edist = oracle.c.knn2(q, t)
     assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+
+
+def test_knn2_extreme_distances(gctx, matcher):
+    """Distances 0 and 256 (all bits equal / all bits different) and rows of all zeros / all ones."""
+    rng = np.random.default_rng(77)
+    t = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    t[3] = 0
+    t[40] = 255
+    q = np.concatenate([t[:5], 255 - t[:5], np.zeros((1, 32), np.uint8), np.full((1, 32), 255, np.uint8)])
+    idx, dist = gctx.knn2(q, t)
+    eidx, edist = oracle.c.knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    assert dist[0, 0] == 0 and dist[10, 0] == 0 and dist[11, 0] == 0
+    far = gctx.knn2(255 - t[:1], t[:1].repeat(2, 0))
+    assert far[1].tolist() == [[256, 256]] and far[0].tolist() == [[0, 1]]
 
 
 def test_ratio_filter_matches_oracle(gctx):

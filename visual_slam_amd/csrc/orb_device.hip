@@ -1245,10 +1245,12 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint8_t* __restri
     reinterpret_cast<uint4*>(x + (size_t)slot * xstride + (size_t)tile * 4096)[threadIdx.x] = o;
 }
 
-__device__ __forceinline__ void top2_insert_f32(float& m1, float& m2, float key)
+// Both steps as v_med3_f32 (max(a, b) = med3(a, b, +inf)): the median intrinsic needs no NaN
+// canonicalisation of its inputs, which a float max of raw accumulator registers would get.
+__device__ __forceinline__ void top2_insert_f32(float& m1, float& m2, float key, float pinf)
 {
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(m1), "v"(m2), "v"(key));
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(m1) : "v"(m1), "v"(key));
+    m2 = __builtin_amdgcn_fmed3f(m1, m2, key);
+    m1 = __builtin_amdgcn_fmed3f(m1, key, pinf);
 }
 
 // Float key after `tiles` tiles of a run that started at train row row0 -> integer key.
@@ -1265,8 +1267,10 @@ constexpr int KNN2_RUN_TILES = 256;   // 8192 rows: the index field of a float k
 
 // QT query tiles (32 queries each) per wave, 4 waves per workgroup; the train tiles stream
 // through a double-buffered 4 KiB LDS tile shared by the 4 waves.
+// At least two workgroups per CU (<= 256 registers per lane): with that bound the compiler keeps
+// the accumulators in ordinary VGPRs, which the top-2 instructions can read directly.
 template <int QT, bool PARTIAL>
-__global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restrict__ xq,
+__global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __restrict__ xq,
                                                         const uint8_t* __restrict__ xt, size_t xq_stride,
                                                         size_t xt_stride, int qslot0, int tslot0,
                                                         const int32_t* __restrict__ qcounts,
@@ -1334,6 +1338,8 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restric
     for (int u = 0; u < QT; ++u) { k1[u] = KEY_NONE; k2[u] = KEY_NONE; m1[u] = -INFINITY; m2[u] = -INFINITY; }
 
     const int scale_one = 0x7F;   // E8M0 exponent 127 = 2^0
+    float pinf = INFINITY;
+    asm volatile("" : "+v"(pinf));   // keep +inf in a register (not a literal operand)
     const uint4* __restrict__ tsrc = reinterpret_cast<const uint4*>(xtf) + (size_t)tbeg * 256 + threadIdx.x;
     uint4 next = make_uint4(0, 0, 0, 0);
     if (tbeg < tend) next = tsrc[0];
@@ -1363,7 +1369,7 @@ __global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restric
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) top2_insert_f32(m1[u], m2[u], acc[i]);
+                for (int i = 0; i < 16; ++i) top2_insert_f32(m1[u], m2[u], acc[i], pinf);
                 m1[u] += 32.0f / 4096.0f;
                 m2[u] += 32.0f / 4096.0f;
             }
