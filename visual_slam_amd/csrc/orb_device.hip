@@ -1245,12 +1245,19 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint8_t* __restri
     reinterpret_cast<uint4*>(x + (size_t)slot * xstride + (size_t)tile * 4096)[threadIdx.x] = o;
 }
 
-// Both steps as v_med3_f32 (max(a, b) = med3(a, b, +inf)): the median intrinsic needs no NaN
-// canonicalisation of its inputs, which a float max of raw accumulator registers would get.
-__device__ __forceinline__ void top2_insert_f32(float& m1, float& m2, float key, float pinf)
+// Two new keys a, b into the running pair m1 >= m2 in three instructions: with s1 >= s2 >= s3 the
+// sorted {m1, a, b}, the new pair is (s1, max(s2, m2)) because m2 <= m1 <= s1.
+// max(x, y) is written med3(x, y, +inf): the median intrinsic needs no NaN canonicalisation of
+// its inputs, which a float max of raw accumulator registers would get.
+// v_max3_f32 has no builtin.  The asm statement also names s2 as an input it does not use: the
+// compiler inserts the wait states between a matrix instruction and the first vector instruction
+// that reads its result only for instructions it emitted itself, so the asm must stay behind the
+// med3 that reads the same two accumulator registers.
+__device__ __forceinline__ void top2_insert2_f32(float& m1, float& m2, float a, float b, float pinf)
 {
-    m2 = __builtin_amdgcn_fmed3f(m1, m2, key);
-    m1 = __builtin_amdgcn_fmed3f(m1, key, pinf);
+    const float s2 = __builtin_amdgcn_fmed3f(m1, a, b);
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(m1), "v"(a), "v"(b), "v"(s2));
+    m2 = __builtin_amdgcn_fmed3f(s2, m2, pinf);
 }
 
 // Float key after `tiles` tiles of a run that started at train row row0 -> integer key.
@@ -1356,22 +1363,27 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
                 const uint4 v = stage[buf][ks * 64 + lane];
                 a[ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
             }
-            v16f c0 = cin;
-            if ((t + 1) * 32 > nt) {                  // last, partial tile: rows past nt never win
+            auto tile = [&](const v16f& c0) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[u], m2[u], acc[i], acc[i + 1], pinf);
+                    m1[u] += 32.0f / 4096.0f;
+                    m2[u] += 32.0f / 4096.0f;
+                }
+            };
+            if ((t + 1) * 32 <= nt) {
+                tile(cin);
+            } else {                                  // last, partial tile: rows past nt never win
+                v16f c0 = cin;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
-            }
-#pragma unroll
-            for (int u = 0; u < QT; ++u) {
-                v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) top2_insert_f32(m1[u], m2[u], acc[i], pinf);
-                m1[u] += 32.0f / 4096.0f;
-                m2[u] += 32.0f / 4096.0f;
+                tile(c0);
             }
             ++run_tiles;
             if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
