@@ -756,57 +756,85 @@ __device__ __forceinline__ int wave_total(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// 4 aligned bytes at a 32-bit byte offset from a wave-uniform base (scalar base + vector offset).
+__device__ __forceinline__ uint32_t load_u32_at(const uint8_t* __restrict__ base, uint32_t off)
+{
+    return *reinterpret_cast<const uint32_t*>(base + off);
+}
+
 // Patch moments of one keypoint, all 64 lanes cooperating.  Returns wave-uniform totals.
-// Fast path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned frame): the 31 columns
+// Dword path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned frame): the 31 columns
 // x-15 .. x+15 lie inside 9 aligned dwords; lane = 9 * rowgroup + dword, seven row groups walk the
 // 31 rows in five steps.  Per dword: bytes outside the 31 columns are masked to zero, then
 // m00 += sum of bytes (v_sad_u8), m10' += bytes . (u + 16) (v_dot4_u32_u8), m01 += v * rowsum.
-__device__ __forceinline__ void patch_moments(const uint8_t* __restrict__ img, int H, int W, int x, int y,
-                                              int lane, bool dwords, int& t00, int& t10, int& t01)
+// All five loads of a lane are issued together; a patch that lies inside the image (the common
+// case, decided once per keypoint) needs no per-row bounds handling.
+__device__ __forceinline__ void patch_moments_dwords(const uint8_t* __restrict__ img, int H, int W, int x,
+                                                     int y, int dw, int rg, int& t00, int& t10, int& t01)
 {
-    int s00 = 0, s10 = 0, s01 = 0;
-    if (dwords) {
-        const int r = (x - 15) & 3;
-        const int xa = (x - 15) - r;              // aligned start column (may be negative)
-        const int dw = lane % 9, rg = lane / 9;   // lane 63: rg = 7, never a valid row group
-        const int t0 = 4 * dw;                    // t = t0 + b is the column offset from xa; valid iff r <= t <= 30 + r
-        uint32_t mask = 0xFFFFFFFFu;
-        const int lo = r - t0;                    // bytes below lo are left of the patch
-        if (lo > 0) mask = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
-        const int hi = 30 + r - t0;               // last valid byte
-        if (hi < 3) mask &= hi < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - hi)));
-        // weights u + 16 = t - r + 1 per byte.  In the first dword the bytes left of the patch would
-        // get negative weights (their borrows would spill into valid bytes), so that word is the
-        // r = 0 pattern {1,2,3,4} shifted up by r bytes; elsewhere the base is >= 2.
-        const uint32_t wts = dw == 0 ? (0x04030201u << (8 * r))
-                                     : (uint32_t)(t0 - r + 1) * 0x01010101u + 0x03020100u;
-        const int gx = xa + t0;
-        const bool colok = rg < 7 && gx >= 0 && gx < W && mask != 0u;
+    const int r = (x - 15) & 3;
+    const int xa = (x - 15) - r;              // aligned start column (may be negative)
+    const int t0 = 4 * dw;                    // t = t0 + b is the column offset from xa; valid iff r <= t <= 30 + r
+    uint32_t mask = 0xFFFFFFFFu;
+    const int lo = r - t0;                    // bytes below lo are left of the patch
+    if (lo > 0) mask = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
+    const int hi = 30 + r - t0;               // last valid byte
+    if (hi < 3) mask &= hi < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - hi)));
+    if (rg >= 7) mask = 0u;                   // lane 63 repeats lane 0's addresses and contributes nothing
+    // weights u + 16 = t - r + 1 per byte.  In the first dword the bytes left of the patch would
+    // get negative weights (their borrows would spill into valid bytes), so that word is the
+    // r = 0 pattern {1,2,3,4} shifted up by r bytes; elsewhere the base is >= 2.
+    const uint32_t wts = dw == 0 ? (0x04030201u << (8 * r))
+                                 : (uint32_t)(t0 - r + 1) * 0x01010101u + 0x03020100u;
+    const int rgc = rg >= 7 ? 0 : rg;
+    const int gx = xa + t0, gy0 = y - 15 + rgc;
+    uint32_t pix[5];
+    if (xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H) {
+        const uint32_t off = (uint32_t)(gy0 * W + gx);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) pix[it] = load_u32_at(img, off + (uint32_t)(7 * it * W));
+        // rows 28 .. 34: only row groups 0 .. 2 are still inside the patch
+        const uint32_t v = load_u32_at(img, rgc < 3 ? off + (uint32_t)(28 * W) : off);
+        pix[4] = rgc < 3 ? v : 0u;
+    } else {
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
-            const int row = rg + 7 * it;
-            const int gy = y - 15 + row;
-            uint32_t pix = 0;
-            if (colok && row < 31 && gy >= 0 && gy < H)
-                pix = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + gx) & mask;
-            const int rs = (int)__builtin_amdgcn_sad_u8(pix, 0u, 0u);
-            s00 += rs;
-            s10 = (int)__builtin_amdgcn_udot4(pix, wts, (uint32_t)s10, false);
-            s01 += (row - 15) * rs;
+            const int row = rgc + 7 * it, gy = gy0 + 7 * it;
+            const bool ok = row < 31 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx) : 0u);
+            pix[it] = ok ? v : 0u;
         }
-        s10 -= 16 * s00;
-    } else {
+    }
+    int s00 = 0, s10 = 0, s01 = 0;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const uint32_t pm = pix[it] & mask;
+        const int rs = (int)__builtin_amdgcn_sad_u8(pm, 0u, 0u);
+        s00 += rs;
+        s10 = (int)__builtin_amdgcn_udot4(pm, wts, (uint32_t)s10, false);
+        s01 += __mul24(rgc + 7 * it - 15, rs);
+    }
+    s10 -= 16 * s00;
+    t00 = wave_total(s00);
+    t10 = wave_total(s10);
+    t01 = wave_total(s01);
+}
+
+// Any width / alignment: one byte per lane and step.
+__device__ __forceinline__ void patch_moments_bytes(const uint8_t* __restrict__ img, int H, int W, int x,
+                                                    int y, int lane, int& t00, int& t10, int& t01)
+{
+    int s00 = 0, s10 = 0, s01 = 0;
 #pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            const int q = lane + 64 * j;      // 0 .. 960 walks the 31x31 square row-major
-            const int v = q / 31, u = q - v * 31;
-            const int yy = y + v - 15, xx = x + u - 15;
-            if (q < 961 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const int I = img[(size_t)yy * W + xx];
-                s00 += I;
-                s10 += (u - 15) * I;
-                s01 += (v - 15) * I;
-            }
+    for (int j = 0; j < 16; ++j) {
+        const int q = lane + 64 * j;      // 0 .. 960 walks the 31x31 square row-major
+        const int v = q / 31, u = q - v * 31;
+        const int yy = y + v - 15, xx = x + u - 15;
+        if (q < 961 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int I = img[(size_t)yy * W + xx];
+            s00 += I;
+            s10 += (u - 15) * I;
+            s01 += (v - 15) * I;
         }
     }
     t00 = wave_total(s00);
@@ -814,35 +842,46 @@ __device__ __forceinline__ void patch_moments(const uint8_t* __restrict__ img, i
     t01 = wave_total(s01);
 }
 
-// Staging of one keypoint's 43-row x 12-dword window (aligned start column xa, first row y0):
-// lane = 12 * rs + dw for lanes 0..59, row = rs + 5 * it.
-constexpr int PATCH_ROWS = 43, PATCH_DW = 12;
+// Staging of one keypoint's 44-row x 12-dword window (aligned start column xa, even first row y0:
+// the 43 rows / columns a sample can reach plus alignment) into LDS rows of 64 bytes:
+// lane = 12 * rs + dw, row = rs + 5 * it.  Lanes 60..63 repeat lanes 0..3.
+constexpr int WIN_ROWS = 44, WIN_DW = 12, WIN_PITCH_DW = 16;
+constexpr int WIN_UINT4 = WIN_ROWS * WIN_PITCH_DW / 4;      // 172
+constexpr int ROT_UINT4 = 32;                               // 31 rotation-table entries of 16 bytes
 
 __device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int H, int W, int xa, int y0,
                                            int dw, int rs, uint32_t (&regs)[9])
 {
-    const int gx = xa + 4 * dw;
-    const bool colok = rs < 5 && gx >= 0 && gx < W;
+    const int gx = xa + 4 * dw, gy0 = y0 + rs;
+    if (xa >= 0 && xa + 4 * WIN_DW <= W && y0 >= 0 && y0 + WIN_ROWS <= H) {
+        const uint32_t off = (uint32_t)(gy0 * W + gx);
 #pragma unroll
-    for (int it = 0; it < 9; ++it) {
-        const int row = rs + 5 * it, gy = y0 + row;
-        uint32_t v = 0;
-        if (colok && row < PATCH_ROWS && gy >= 0 && gy < H)
-            v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + gx);
-        regs[it] = v;
-    }
-}
-
-__device__ __forceinline__ void stage_write(uint32_t* lds, int dw, int rs, const uint32_t (&regs)[9])
-{
-    if (rs < 5) {
+        for (int it = 0; it < 8; ++it) regs[it] = load_u32_at(img, off + (uint32_t)(5 * it * W));
+        // rows 40 .. 44: only rs 0 .. 3 are inside the window (the other is not written)
+        regs[8] = load_u32_at(img, rs < 4 ? off + (uint32_t)(40 * W) : off);
+    } else {
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
-            const int row = rs + 5 * it;
-            if (row < PATCH_ROWS) lds[row * PATCH_DW + dw] = regs[it];
+            const int row = rs + 5 * it, gy = gy0 + 5 * it;
+            const bool ok = row < WIN_ROWS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx) : 0u);
+            regs[it] = ok ? v : 0u;
         }
     }
 }
+
+__device__ __forceinline__ void stage_write(uint32_t* win, int dw, int rs, const uint32_t (&regs)[9])
+{
+    uint32_t* const p = win + rs * WIN_PITCH_DW + dw;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) p[5 * it * WIN_PITCH_DW] = regs[it];
+    if (rs < 4) p[40 * WIN_PITCH_DW] = regs[8];
+}
+
+// 1.5 * 2^23: adding it to a float |t| < 2^22 leaves rint(t) (ties to even, the cvRound of the
+// reference, src/orb.cpp:203-206) in the low mantissa bits: bits(t + magic) = 0x4B400000 + rint(t).
+constexpr float RND_MAGIC = 12582912.0f;
+constexpr uint32_t RND_MAGIC_BITS = 0x4B400000u;
 
 template <int KPW>
 __global__ __launch_bounds__(256) void orient_describe_kernel(
@@ -875,11 +914,21 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
         if (mine) angle = angle_in[k0 + lane];
     } else {
         int m00 = 0, m10 = 0, m01 = 0;
-        for (int j = 0; j < nk; ++j) {
-            const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
-            int t00, t10, t01;
-            patch_moments(img, H, W, x, y, lane, dwords != 0, t00, t10, t01);
-            if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
+        if (dwords) {
+            const int dw = lane % 9, rg = lane / 9;   // lane 63: rg = 7
+            for (int j = 0; j < nk; ++j) {
+                const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+                int t00, t10, t01;
+                patch_moments_dwords(img, H, W, x, y, dw, rg, t00, t10, t01);
+                if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
+            }
+        } else {
+            for (int j = 0; j < nk; ++j) {
+                const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+                int t00, t10, t01;
+                patch_moments_bytes(img, H, W, x, y, lane, t00, t10, t01);
+                if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
+            }
         }
         // ---- phase B (first half): one atan2 per lane ----
         angle = angle_from_moments(m00, m10, m01);
@@ -903,73 +952,96 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
     const int c_lo = __double2loint(c), c_hi = __double2hiint(c);
     const int s_lo = __double2loint(s), s_hi = __double2hiint(s);
 
-    // this lane's four test pairs (one per round), as doubles
-    double px1[4], py1[4], px2[4], py2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
-        px1[r] = (double)(int8_t)(q & 255u);
-        py1[r] = (double)(int8_t)((q >> 8) & 255u);
-        px2[r] = (double)(int8_t)((q >> 16) & 255u);
-        py2[r] = (double)(int8_t)(q >> 24);
-    }
-
     // ---- phase C: descriptors, one keypoint at a time ----
     unsigned long long todo = __ballot(slot >= 0);
     if (dwords) {
-        // The 512 samples of a keypoint fall in the 43x43 window around it (|rotated offset| <=
+        // The 512 samples of a keypoint fall in the 43x43 square around it (|rotated offset| <=
         // 21.3).  Scattered byte gathers from global memory cost one cache line per lane; instead the
         // window is staged into this wave's LDS slab with coalesced dword reads (rows of 12 aligned
-        // dwords = 48 bytes, zero where outside the image -- which is also what an out-of-image
-        // sample must read, reference src/orb.cpp:211-217) and the samples are gathered from LDS.
-        // The next keypoint's window is loaded into registers while this one is evaluated.
-        __shared__ uint32_t slab[4][2][PATCH_ROWS * PATCH_DW];
-        uint32_t* const lds0 = slab[wave_id()][0];
-        uint32_t* const lds1 = slab[wave_id()][1];
-        const int dw = lane % PATCH_DW, rs = lane / PATCH_DW;     // lanes 60..63 idle while staging
+        // dwords, zero where outside the image -- which is also what an out-of-image sample must
+        // read, reference src/orb.cpp:211-217) and the samples are gathered from LDS.  The next
+        // keypoint's window is loaded into registers while this one is evaluated.
+        //
+        // Rotation: a pattern coordinate is an integer k in -15 .. 15 and the reference forms
+        // k * cos and k * sin in double (src/orb.cpp:195-199).  Lanes 0 .. 30 compute those 31
+        // product pairs once per keypoint into an LDS table; every sample then takes its four
+        // products from the table (two 16-byte reads) instead of multiplying.
+        //
+        // One window and one table per wave are enough: a wave's LDS operations execute in program
+        // order, so the next keypoint's stores cannot overtake this keypoint's reads.
+        __shared__ uint4 slab[4][WIN_UINT4 + ROT_UINT4];
+        const int wv = wave_id();
+        uint32_t* const win = reinterpret_cast<uint32_t*>(slab[wv]);
+        const uint8_t* const pb = reinterpret_cast<const uint8_t*>(slab[wv]);
+        const uint8_t* const rot = reinterpret_cast<const uint8_t*>(slab[wv] + WIN_UINT4);
+        const int dw = lane % WIN_DW, rs = (lane / WIN_DW) % 5;
+        // this lane's table entries, one test pair per round
+        const double2 *t1x[4], *t1y[4], *t2x[4], *t2y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
+            t1x[r] = reinterpret_cast<const double2*>(rot) + ((int)(int8_t)(q & 255u) + 15);
+            t1y[r] = reinterpret_cast<const double2*>(rot) + ((int)(int8_t)((q >> 8) & 255u) + 15);
+            t2x[r] = reinterpret_cast<const double2*>(rot) + ((int)(int8_t)((q >> 16) & 255u) + 15);
+            t2y[r] = reinterpret_cast<const double2*>(rot) + ((int)(int8_t)(q >> 24) + 15);
+        }
+        const double kd = (double)((lane < 31 ? lane : 30) - 15);
         uint32_t regs[9];
         int j = __builtin_ctzll(todo);
         todo &= todo - 1;
         {
             const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
-            stage_load(img, H, W, (x - 21) & ~3, y - 21, dw, rs, regs);
+            stage_load(img, H, W, (x - 21) & ~3, (y - 21) & ~1, dw, rs, regs);
         }
-        int cur = 0;
         while (true) {
-            uint32_t* const lds = cur ? lds1 : lds0;
-            stage_write(lds, dw, rs, regs);
+            stage_write(win, dw, rs, regs);
             const int xj = __builtin_amdgcn_readlane(p.x, j), yj = __builtin_amdgcn_readlane(p.y, j);
             const int sj = __builtin_amdgcn_readlane(slot, j);
             const double cj = __hiloint2double(__builtin_amdgcn_readlane(c_hi, j), __builtin_amdgcn_readlane(c_lo, j));
             const double sn = __hiloint2double(__builtin_amdgcn_readlane(s_hi, j), __builtin_amdgcn_readlane(s_lo, j));
+            if (lane < 31) {
+                double2 e;
+                e.x = kd * cj;
+                e.y = kd * sn;
+                reinterpret_cast<double2*>(slab[wv] + WIN_UINT4)[lane] = e;
+            }
             const bool more = todo != 0ull;
             int jn = j;
             if (more) {
                 jn = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int x = __builtin_amdgcn_readlane(p.x, jn), y = __builtin_amdgcn_readlane(p.y, jn);
-                stage_load(img, H, W, (x - 21) & ~3, y - 21, dw, rs, regs);
+                stage_load(img, H, W, (x - 21) & ~3, (y - 21) & ~1, dw, rs, regs);
             }
+            unsigned long long bal[4] = {0ull, 0ull, 0ull, 0ull};
             // A non-finite angle (possible only for caller-supplied angles) makes every coordinate
             // NaN; the reference's cvRound then yields INT_MIN, outside the image: all samples read 0.
-            const bool finite = fabs(cj) <= 1.0 && fabs(sn) <= 1.0;
-            const float cx = (float)xj, cy = (float)yj;
-            const int xa = (xj - 21) & ~3, y0 = yj - 21;
-            const uint8_t* const pb = reinterpret_cast<const uint8_t*>(lds);
-            unsigned long long bal[4];
+            if (fabs(cj) <= 1.0 && fabs(sn) <= 1.0) {
+                // Rounding and window-relative indexing in one float add: for an integer m,
+                // (t + (magic - m)) has the bits 0x4B400000 + rint(t) - m -- for EVEN m: the add rounds
+                // a tie to an even sum, which is an even rint(t) only then.  With m = the window's
+                // first column / row (multiples of 4 / 2) the low bits are the sample's column / row
+                // in the window; the 0x4B400000 parts of row * 64 + column are a constant folded
+                // into the address.
+                float cx = (float)xj, cy = (float)yj;
+                float mx = RND_MAGIC - (float)((xj - 21) & ~3), my = RND_MAGIC - (float)((yj - 21) & ~1);
+                asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my));   // vector copies: scalar operands halve the add rate
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x1r = (float)(px1[r] * cj - py1[r] * sn);
-                const float y1r = (float)(px1[r] * sn + py1[r] * cj);
-                const float x2r = (float)(px2[r] * cj - py2[r] * sn);
-                const float y2r = (float)(px2[r] * sn + py2[r] * cj);
-                const int ax = __float2int_rn(cx + x1r), ay = __float2int_rn(cy + y1r);
-                const int bx = __float2int_rn(cx + x2r), by = __float2int_rn(cy + y2r);
-                int i1 = (ay - y0) * (PATCH_DW * 4) + (ax - xa);
-                int i2 = (by - y0) * (PATCH_DW * 4) + (bx - xa);
-                if (!finite) { i1 = 0; i2 = 0; }
-                const int v1 = pb[i1], v2 = pb[i2];
-                bal[r] = __ballot(finite && v1 < v2);
+                for (int r = 0; r < 4; ++r) {
+                    const double2 e1x = *t1x[r], e1y = *t1y[r], e2x = *t2x[r], e2y = *t2y[r];
+                    const float x1r = (float)(e1x.x - e1y.y);     // px1 * c - py1 * s
+                    const float y1r = (float)(e1x.y + e1y.x);     // px1 * s + py1 * c
+                    const float x2r = (float)(e2x.x - e2y.y);
+                    const float y2r = (float)(e2x.y + e2y.x);
+                    const uint32_t ax = __float_as_uint((cx + x1r) + mx);
+                    const uint32_t ay = __float_as_uint((cy + y1r) + my);
+                    const uint32_t bx = __float_as_uint((cx + x2r) + mx);
+                    const uint32_t by = __float_as_uint((cy + y2r) + my);
+                    const uint32_t i1 = ((ay << 6) + ax) - RND_MAGIC_BITS * 65u;
+                    const uint32_t i2 = ((by << 6) + bx) - RND_MAGIC_BITS * 65u;
+                    const int v1 = pb[i1], v2 = pb[i2];
+                    bal[r] = __ballot(v1 < v2);
+                }
             }
             // lanes 0..3 store one 8-byte word each: 32 contiguous bytes per descriptor
             if (lane < 4) {
@@ -978,9 +1050,18 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
             }
             if (!more) break;
             j = jn;
-            cur ^= 1;
         }
     } else {
+        // this lane's four test pairs (one per round), as doubles
+        double px1[4], py1[4], px2[4], py2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
+            px1[r] = (double)(int8_t)(q & 255u);
+            py1[r] = (double)(int8_t)((q >> 8) & 255u);
+            px2[r] = (double)(int8_t)((q >> 16) & 255u);
+            py2[r] = (double)(int8_t)(q >> 24);
+        }
         while (todo) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
