@@ -762,18 +762,43 @@ __device__ __forceinline__ uint32_t load_u32_at(const uint8_t* __restrict__ base
     return *reinterpret_cast<const uint32_t*>(base + off);
 }
 
-// Patch moments of one keypoint, all 64 lanes cooperating.  Returns wave-uniform totals.
+// Patch moments of one keypoint, all 64 lanes cooperating.
 // Dword path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned frame): the 31 columns
 // x-15 .. x+15 lie inside 9 aligned dwords; lane = 9 * rowgroup + dword, seven row groups walk the
 // 31 rows in five steps.  Per dword: bytes outside the 31 columns are masked to zero, then
 // m00 += sum of bytes (v_sad_u8), m10' += bytes . (u + 16) (v_dot4_u32_u8), m01 += v * rowsum.
-// All five loads of a lane are issued together; a patch that lies inside the image (the common
-// case, decided once per keypoint) needs no per-row bounds handling.
-__device__ __forceinline__ void patch_moments_dwords(const uint8_t* __restrict__ img, int H, int W, int x,
-                                                     int y, int dw, int rg, int& t00, int& t10, int& t01)
+// Split in two so that the caller can have the next keypoint's loads in flight while this one is
+// reduced.  All five loads of a lane are issued together; a patch that lies inside the image (the
+// common case, decided once per keypoint) needs no per-row bounds handling.
+__device__ __forceinline__ void patch_load_dwords(const uint8_t* __restrict__ img, int H, int W, int x, int y,
+                                                  int dw, int rgc, uint32_t (&pix)[5])
+{
+    const int xa = (x - 15) & ~3;             // aligned start column (may be negative)
+    const int gx = xa + 4 * dw, gy0 = y - 15 + rgc;
+    if (xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H) {
+        const uint32_t off = (uint32_t)(gy0 * W + gx);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) pix[it] = load_u32_at(img, off + (uint32_t)(7 * it * W));
+        // rows 28 .. 34: only row groups 0 .. 2 are still inside the patch (the reduction ignores
+        // pix[4] of the others; nothing here may use a loaded value, or the wait for the loads
+        // would land in front of the previous keypoint's reduction)
+        pix[4] = load_u32_at(img, rgc < 3 ? off + (uint32_t)(28 * W) : off);
+    } else {
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int row = rgc + 7 * it, gy = gy0 + 7 * it;
+            const bool ok = row < 31 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx) : 0u);
+            pix[it] = ok ? v : 0u;
+        }
+    }
+}
+
+// Returns wave-uniform totals.
+__device__ __forceinline__ void patch_reduce_dwords(const uint32_t (&pix)[5], int x, int dw, int rg, int rgc,
+                                                    int& t00, int& t10, int& t01)
 {
     const int r = (x - 15) & 3;
-    const int xa = (x - 15) - r;              // aligned start column (may be negative)
     const int t0 = 4 * dw;                    // t = t0 + b is the column offset from xa; valid iff r <= t <= 30 + r
     uint32_t mask = 0xFFFFFFFFu;
     const int lo = r - t0;                    // bytes below lo are left of the patch
@@ -786,29 +811,10 @@ __device__ __forceinline__ void patch_moments_dwords(const uint8_t* __restrict__
     // r = 0 pattern {1,2,3,4} shifted up by r bytes; elsewhere the base is >= 2.
     const uint32_t wts = dw == 0 ? (0x04030201u << (8 * r))
                                  : (uint32_t)(t0 - r + 1) * 0x01010101u + 0x03020100u;
-    const int rgc = rg >= 7 ? 0 : rg;
-    const int gx = xa + t0, gy0 = y - 15 + rgc;
-    uint32_t pix[5];
-    if (xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H) {
-        const uint32_t off = (uint32_t)(gy0 * W + gx);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) pix[it] = load_u32_at(img, off + (uint32_t)(7 * it * W));
-        // rows 28 .. 34: only row groups 0 .. 2 are still inside the patch
-        const uint32_t v = load_u32_at(img, rgc < 3 ? off + (uint32_t)(28 * W) : off);
-        pix[4] = rgc < 3 ? v : 0u;
-    } else {
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int row = rgc + 7 * it, gy = gy0 + 7 * it;
-            const bool ok = row < 31 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx) : 0u);
-            pix[it] = ok ? v : 0u;
-        }
-    }
     int s00 = 0, s10 = 0, s01 = 0;
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
-        const uint32_t pm = pix[it] & mask;
+        const uint32_t pm = pix[it] & (it == 4 && rgc >= 3 ? 0u : mask);
         const int rs = (int)__builtin_amdgcn_sad_u8(pm, 0u, 0u);
         s00 += rs;
         s10 = (int)__builtin_amdgcn_udot4(pm, wts, (uint32_t)s10, false);
@@ -894,34 +900,88 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
     const uint32_t item = xcd_contiguous_item();
     const int f = (int)(item / (uint32_t)nbf);
     const int blk = (int)(item - (uint32_t)f * (uint32_t)nbf);
-    const int base = (blk * 4 + wave_id()) * KPW;
+    const int wg_base = blk * (4 * KPW);
     int n = counts[2 * f];
     n = n < cap ? n : cap;
-    if (base >= n) return;
-    const int nk = (n - base) < KPW ? (n - base) : KPW;
-    const int lane = lane_id();
+    if (wg_base >= n) return;                 // uniform over the workgroup
+    const int wg_n = (n - wg_base) < 4 * KPW ? (n - wg_base) : 4 * KPW;
+    const int lane = lane_id(), wave = wave_id();
     const uint8_t* img = gray + (size_t)f * H * W;
-    const size_t k0 = (size_t)f * cap + base;
+    const size_t k0 = (size_t)f * cap + wg_base;
 
-    // this lane's keypoint (position `lane` of the batch)
-    const bool mine = lane < nk;
-    const int2 p = mine ? kpxy[k0 + lane] : make_int2(0, 0);
-    const int slot = (mine && desc) ? kpslot[k0 + lane] : -1;
+    // The workgroup owns 4 * KPW consecutive keypoints of the scan order: a band of image rows
+    // across the full width, in which consecutive keypoints are hundreds of pixels apart.  They
+    // are processed in order of x instead (counting sort on 256 column buckets; the order inside a
+    // bucket is whatever the atomics give and does not matter, every result goes to the keypoint's
+    // own row).  Sorted position 4 * l + w goes to lane l of wave w, so the four waves sweep the
+    // band from left to right together and successive windows overlap; that turns most of the
+    // window and patch reads into L2 hits.
+    __shared__ int bucket_count[256];
+    __shared__ int wave_sum_lds[4];
+    __shared__ uint16_t order[256];
+    int kidx = -1;                            // this lane's keypoint, relative to wg_base
+    {
+        const int t = threadIdx.x;
+        bucket_count[t] = 0;
+        __syncthreads();
+        const int shift = W > 256 ? 32 - __builtin_clz((unsigned)(W - 1)) - 8 : 0;
+        int bkt = 0, rank = 0;
+        if (t < wg_n) {
+            bkt = kpxy[k0 + t].x >> shift;
+            bkt = bkt < 0 ? 0 : (bkt > 255 ? 255 : bkt);
+            rank = atomicAdd(&bucket_count[bkt], 1);
+        }
+        __syncthreads();
+        const int cnt = bucket_count[t];
+        const int incl = wave_incl_scan(cnt, lane);
+        if (lane == 63) wave_sum_lds[wave] = incl;
+        __syncthreads();
+        int before = incl - cnt;
+        for (int w = 0; w < wave; ++w) before += wave_sum_lds[w];
+        bucket_count[t] = before;             // exclusive prefix: first sorted position of bucket t
+        __syncthreads();
+        if (t < wg_n) order[bucket_count[bkt] + rank] = (uint16_t)t;
+        __syncthreads();
+        const int pos = 4 * lane + wave;
+        if (lane < KPW && pos < wg_n) kidx = order[pos];
+    }
+    const int nk = (int)__builtin_popcountll(__ballot(kidx >= 0));   // lanes 0 .. nk-1 hold keypoints
+    if (nk == 0) return;
+
+    // this lane's keypoint
+    const bool mine = kidx >= 0;
+    const int2 p = mine ? kpxy[k0 + kidx] : make_int2(0, 0);
+    const int slot = (mine && desc) ? kpslot[k0 + kidx] : -1;
 
     // ---- phase A: moments, one keypoint at a time ----
     float angle = 0.0f;
     if (angle_in) {
-        if (mine) angle = angle_in[k0 + lane];
+        if (mine) angle = angle_in[k0 + kidx];
     } else {
         int m00 = 0, m10 = 0, m01 = 0;
         if (dwords) {
             const int dw = lane % 9, rg = lane / 9;   // lane 63: rg = 7
-            for (int j = 0; j < nk; ++j) {
-                const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+            const int rgc = rg >= 7 ? 0 : rg;
+            // Two register sets in ping-pong (no copies: a copy would wait for the loads it moves).
+            uint32_t pa[5], pb[5];
+            auto fetch = [&](int j, uint32_t (&pix)[5]) {
+                patch_load_dwords(img, H, W, __builtin_amdgcn_readlane(p.x, j), __builtin_amdgcn_readlane(p.y, j),
+                                  dw, rgc, pix);
+            };
+            auto reduce = [&](int j, const uint32_t (&pix)[5]) {
                 int t00, t10, t01;
-                patch_moments_dwords(img, H, W, x, y, dw, rg, t00, t10, t01);
+                patch_reduce_dwords(pix, __builtin_amdgcn_readlane(p.x, j), dw, rg, rgc, t00, t10, t01);
                 if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
+            };
+            fetch(0, pa);
+            int j = 0;
+            for (; j + 2 <= nk; j += 2) {
+                fetch(j + 1, pb);
+                reduce(j, pa);
+                if (j + 2 < nk) fetch(j + 2, pa);
+                reduce(j + 1, pb);
             }
+            if (j < nk) reduce(j, pa);
         } else {
             for (int j = 0; j < nk; ++j) {
                 const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
@@ -934,14 +994,14 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
         angle = angle_from_moments(m00, m10, m01);
     }
     if (mine) {
-        if (angle_out) angle_out[k0 + lane] = angle;
+        if (angle_out) angle_out[k0 + kidx] = angle;
         if (kp7) {
             // [x, y, size, angle, response, octave, class_id] (reference src/main_interface.cpp:46-52)
-            float* row = kp7 + (k0 + lane) * 7;
+            float* row = kp7 + (k0 + kidx) * 7;
             row[0] = (float)p.x; row[1] = (float)p.y; row[2] = 7.0f; row[3] = angle;
             row[4] = 0.0f; row[5] = 0.0f; row[6] = -1.0f;
         }
-        if (slot >= 0 && valid_idx) valid_idx[(size_t)f * cap + slot] = base + lane;
+        if (slot >= 0 && valid_idx) valid_idx[(size_t)f * cap + slot] = wg_base + kidx;
     }
     if (!desc) return;
     if (__ballot(slot >= 0) == 0ull) return;   // (lanes beyond the batch carry slot = -1)
