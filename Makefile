@@ -27,7 +27,14 @@ $(MODULE): $(CSRC)/orb_module.cpp include/orbamd.h $(LIB)
 oracle:
 	$(MAKE) -s -C oracle
 
+# Stand-alone measurement programs (not part of the library).
+MICRO := build/valu_rates build/valu_peak build/mfma_fp4_probe build/mfma_valu_coexec
+micro: $(MICRO)
+build/%: $(CSRC)/micro/%.hip
+	mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -Wno-unused-result -o $@ $<
+
 clean:
 	rm -f $(LIB) $(MODULE) oracle/liborb_oracle.so
 
-.PHONY: all oracle clean
+.PHONY: all oracle micro clean

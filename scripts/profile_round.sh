@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collects the profiles that bench.py's roofline block cites: kernel durations of the default
+# bench.py run, and HBM traffic per kernel (FETCH_SIZE and WRITE_SIZE in separate PMC passes).
+#   bash scripts/profile_round.sh <tag>      (on the GPU box; results under gpurun_out/prof_<tag>/)
+set -e
+TAG=${1:-run}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $R
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 bench.py > $OUT/bench_under_rocprof.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/write.log 2>&1
+python3 scripts/collect_traffic.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/traffic.json > $OUT/traffic.txt
+cat $OUT/traffic.txt
