@@ -762,68 +762,91 @@ __device__ __forceinline__ uint32_t load_u32_at(const uint8_t* __restrict__ base
     return *reinterpret_cast<const uint32_t*>(base + off);
 }
 
-// Patch moments of one keypoint, all 64 lanes cooperating.
-// Dword path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned frame): the 31 columns
-// x-15 .. x+15 lie inside 9 aligned dwords; lane = 9 * rowgroup + dword, seven row groups walk the
-// 31 rows in five steps.  Per dword: bytes outside the 31 columns are masked to zero, then
-// m00 += sum of bytes (v_sad_u8), m10' += bytes . (u + 16) (v_dot4_u32_u8), m01 += v * rowsum.
-// Split in two so that the caller can have the next keypoint's loads in flight while this one is
-// reduced.  All five loads of a lane are issued together; a patch that lies inside the image (the
-// common case, decided once per keypoint) needs no per-row bounds handling.
-__device__ __forceinline__ void patch_load_dwords(const uint8_t* __restrict__ img, int H, int W, int x, int y,
-                                                  int dw, int rgc, uint32_t (&pix)[5])
+// 12 bytes from a 4-byte-aligned address in one load.
+struct __attribute__((aligned(4))) Tri32 { uint32_t v[3]; };
+__device__ __forceinline__ Tri32 load_tri_at(const uint8_t* __restrict__ base, uint32_t off)
 {
-    const int xa = (x - 15) & ~3;             // aligned start column (may be negative)
-    const int gx = xa + 4 * dw, gy0 = y - 15 + rgc;
-    if (xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H) {
-        const uint32_t off = (uint32_t)(gy0 * W + gx);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) pix[it] = load_u32_at(img, off + (uint32_t)(7 * it * W));
-        // rows 28 .. 34: only row groups 0 .. 2 are still inside the patch (the reduction ignores
-        // pix[4] of the others; nothing here may use a loaded value, or the wait for the loads
-        // would land in front of the previous keypoint's reduction)
-        pix[4] = load_u32_at(img, rgc < 3 ? off + (uint32_t)(28 * W) : off);
-    } else {
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int row = rgc + 7 * it, gy = gy0 + 7 * it;
-            const bool ok = row < 31 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx) : 0u);
-            pix[it] = ok ? v : 0u;
-        }
-    }
+    return *reinterpret_cast<const Tri32*>(base + off);
 }
 
-// Returns wave-uniform totals.
-__device__ __forceinline__ void patch_reduce_dwords(const uint32_t (&pix)[5], int x, int dw, int rg, int rgc,
-                                                    int& t00, int& t10, int& t01)
+// Patch moments on the dword path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned
+// frame): FOUR keypoints per step, 16 lanes each.  The 31 columns x-15 .. x+15 lie inside 9 aligned
+// dwords starting at xa = (x-15) & ~3.  Lane q of a group = (row slot rs = q / 3, chunk ch = q % 3):
+// it reads dwords 3 ch .. 3 ch + 2 of rows rs, rs + 5, ..., so one load instruction covers five
+// whole 36-byte rows per keypoint (few cache lines per instruction; lane 15 idles).  Per dword:
+// m00 += sum of bytes (v_sad_u8, accumulating), m10' += bytes . (u + 16) (v_dot4_u32_u8); only
+// dwords 0, 7 and 8 contain bytes outside the 31 columns.  m01 += v * rowsum per row.  The three
+// sums are reduced over the 16 lanes of a DPP row (4 steps, against 6 steps over 64 lanes for one
+// keypoint at a time).  The totals come out in lane 15 of each row; (x, y) are per lane.
+__device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ img, int H, int W, int x, int y,
+                                                   bool group_valid, int q, int& s00, int& s10, int& s01)
 {
     const int r = (x - 15) & 3;
-    const int t0 = 4 * dw;                    // t = t0 + b is the column offset from xa; valid iff r <= t <= 30 + r
-    uint32_t mask = 0xFFFFFFFFu;
-    const int lo = r - t0;                    // bytes below lo are left of the patch
-    if (lo > 0) mask = lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
-    const int hi = 30 + r - t0;               // last valid byte
-    if (hi < 3) mask &= hi < 0 ? 0u : (0xFFFFFFFFu >> (8 * (3 - hi)));
-    if (rg >= 7) mask = 0u;                   // lane 63 repeats lane 0's addresses and contributes nothing
-    // weights u + 16 = t - r + 1 per byte.  In the first dword the bytes left of the patch would
-    // get negative weights (their borrows would spill into valid bytes), so that word is the
-    // r = 0 pattern {1,2,3,4} shifted up by r bytes; elsewhere the base is >= 2.
-    const uint32_t wts = dw == 0 ? (0x04030201u << (8 * r))
-                                 : (uint32_t)(t0 - r + 1) * 0x01010101u + 0x03020100u;
-    int s00 = 0, s10 = 0, s01 = 0;
-#pragma unroll
-    for (int it = 0; it < 5; ++it) {
-        const uint32_t pm = pix[it] & (it == 4 && rgc >= 3 ? 0u : mask);
-        const int rs = (int)__builtin_amdgcn_sad_u8(pm, 0u, 0u);
-        s00 += rs;
-        s10 = (int)__builtin_amdgcn_udot4(pm, wts, (uint32_t)s10, false);
-        s01 += __mul24(rgc + 7 * it - 15, rs);
+    const int xa = (x - 15) - r;              // aligned start column (may be negative)
+    const int rs = q < 15 ? q / 3 : 0, ch = q < 15 ? q % 3 : 0;
+    const bool lane_on = group_valid && q < 15;
+    // column offset t = 4 c + byte is inside the patch iff r <= t <= 30 + r: partial dwords are
+    // c = 0 (chunk 0, first), c = 7 and c = 8 (chunk 2, second and third)
+    uint32_t mk[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (ch == 0) mk[0] = 0xFFFFFFFFu << (8 * r);
+    if (ch == 2) {
+        mk[1] = r == 0 ? 0x00FFFFFFu : 0xFFFFFFFFu;
+        mk[2] = r < 2 ? 0u : (r == 2 ? 0x000000FFu : 0x0000FFFFu);
     }
-    s10 -= 16 * s00;
-    t00 = wave_total(s00);
-    t10 = wave_total(s10);
-    t01 = wave_total(s01);
+    if (!lane_on) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; }
+    // weights u + 16 = t - r + 1 per byte.  In dword 0 the bytes left of the patch would get
+    // negative weights (their borrows would spill into valid bytes), so that word is the r = 0
+    // pattern {1,2,3,4} shifted up by r bytes; from dword 1 on every weight is >= 2.
+    uint32_t w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[j] = (uint32_t)(4 * (3 * ch + j) - r + 1) * 0x01010101u + 0x03020100u;
+    if (ch == 0) w[0] = 0x04030201u << (8 * r);
+
+    const int gx = xa + 12 * ch, gy0 = y - 15 + rs;
+    Tri32 pix[7];
+    const bool interior = xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H;
+    if (__all(interior || !group_valid)) {
+        // Lanes without work read the frame's first bytes; their masks are zero.
+        const uint32_t off = lane_on ? (uint32_t)(gy0 * W + gx) : 0u;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) pix[it] = load_tri_at(img, off + (lane_on ? (uint32_t)(5 * it * W) : 0u));
+        // rows 30 .. 34: only row slot 0 is still inside the patch (the others get zero masks below)
+        pix[6] = load_tri_at(img, (lane_on && rs == 0) ? off + (uint32_t)(30 * W) : off);
+    } else {
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int gy = gy0 + 5 * it;
+            const bool rowok = lane_on && rs + 5 * it < 31 && gy >= 0 && gy < H;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool ok = rowok && gx + 4 * j >= 0 && gx + 4 * j < W;
+                const uint32_t v = load_u32_at(img, ok ? (uint32_t)(gy * W + gx + 4 * j) : 0u);
+                pix[it].v[j] = ok ? v : 0u;
+            }
+        }
+    }
+    uint32_t t00 = 0, t10 = 0;
+    int t01 = 0;
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        uint32_t rsum = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t pm = pix[it].v[j] & ((it == 6 && rs != 0) ? 0u : mk[j]);
+            rsum = __builtin_amdgcn_sad_u8(pm, 0u, rsum);
+            t10 = __builtin_amdgcn_udot4(pm, w[j], t10, false);
+        }
+        t00 += rsum;
+        t01 += __mul24(rs + 5 * it - 15, (int)rsum);
+    }
+    s00 = (int)t00;
+    s10 = (int)t10 - 16 * s00;
+    s01 = t01;
+    // sums over each row of 16 lanes; lane 15 of the row ends up with the total
+    s00 = dpp_add<0x111, 0xf>(s00); s10 = dpp_add<0x111, 0xf>(s10); s01 = dpp_add<0x111, 0xf>(s01);
+    s00 = dpp_add<0x112, 0xf>(s00); s10 = dpp_add<0x112, 0xf>(s10); s01 = dpp_add<0x112, 0xf>(s01);
+    s00 = dpp_add<0x114, 0xf>(s00); s10 = dpp_add<0x114, 0xf>(s10); s01 = dpp_add<0x114, 0xf>(s01);
+    s00 = dpp_add<0x118, 0xf>(s00); s10 = dpp_add<0x118, 0xf>(s10); s01 = dpp_add<0x118, 0xf>(s01);
 }
 
 // Any width / alignment: one byte per lane and step.
@@ -960,28 +983,18 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
     } else {
         int m00 = 0, m10 = 0, m01 = 0;
         if (dwords) {
-            const int dw = lane % 9, rg = lane / 9;   // lane 63: rg = 7
-            const int rgc = rg >= 7 ? 0 : rg;
-            // Two register sets in ping-pong (no copies: a copy would wait for the loads it moves).
-            uint32_t pa[5], pb[5];
-            auto fetch = [&](int j, uint32_t (&pix)[5]) {
-                patch_load_dwords(img, H, W, __builtin_amdgcn_readlane(p.x, j), __builtin_amdgcn_readlane(p.y, j),
-                                  dw, rgc, pix);
-            };
-            auto reduce = [&](int j, const uint32_t (&pix)[5]) {
-                int t00, t10, t01;
-                patch_reduce_dwords(pix, __builtin_amdgcn_readlane(p.x, j), dw, rg, rgc, t00, t10, t01);
-                if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
-            };
-            fetch(0, pa);
-            int j = 0;
-            for (; j + 2 <= nk; j += 2) {
-                fetch(j + 1, pb);
-                reduce(j, pa);
-                if (j + 2 < nk) fetch(j + 2, pa);
-                reduce(j + 1, pb);
+            // group g = lane / 16 takes batch position 4 * step + g; the totals of a group come out
+            // in its lane 15 and are handed to the lane that owns the keypoint
+            const int g = lane >> 4, q = lane & 15;
+            const int total_lane = 16 * (lane & 3) + 15;
+            for (int step = 0; 4 * step < nk; ++step) {
+                const int src = 4 * step + g;
+                const int x = __shfl(p.x, src), y = __shfl(p.y, src);
+                int s00, s10, s01;
+                patch_moments_quad(img, H, W, x, y, src < nk, q, s00, s10, s01);
+                const int t00 = __shfl(s00, total_lane), t10 = __shfl(s10, total_lane), t01 = __shfl(s01, total_lane);
+                if ((lane >> 2) == step) { m00 = t00; m10 = t10; m01 = t01; }
             }
-            if (j < nk) reduce(j, pa);
         } else {
             for (int j = 0; j < nk; ++j) {
                 const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
