@@ -131,7 +131,7 @@ def main():
     MW8 = (W + 7) // 8
     alg = {
         # bytes per launch (one launch covers the rank's whole batch)
-        "fast_mask": ("hbm", float(F * (H * W + H * MW8 + 4 * H))),
+        "fast_mask": ("hbm", float(F * (H * W + H * MW8 + 8 * H))),
         "rowcount": ("hbm", float(F * (H * MW8 + 8 * H))),
         "rowscan": ("hbm", float(F * (16 * H + 8))),
         "emit": ("hbm", float(F * H * MW8 + 8 * n.sum())),

@@ -170,14 +170,10 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     FrameSet fs{d_gray, frames, H, W};
     {
         Timed t(c, ORBAMD_K_FAST);
-        launch_fast_mask(fs, (uint32_t*)c->mask.p, c->stream);
+        HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
+        launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
     }
     CHK(post_launch(c, "fast_mask_kernel"));
-    {
-        Timed t(c, ORBAMD_K_ROWCOUNT);
-        launch_rowcount(fs, (const uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
-    }
-    CHK(post_launch(c, "rowcount_kernel"));
     {
         Timed t(c, ORBAMD_K_ROWSCAN);
         launch_rowscan(fs, (const int2*)c->rowcnt.p, (int2*)c->rowoff.p, d_counts, c->stream);

@@ -3,8 +3,8 @@
 // Kernels (one wavefront = 64 lanes throughout):
 //   bgr2gray_kernel         byte stream, 4 pixels per lane
 //   synth_kernel            seeded synthetic frames, 4 pixels per lane
-//   fast_mask_kernel        FAST segment test on LDS-staged tiles -> 1 bit per pixel
-//   rowcount_kernel         per image row: number of corners / of corners that get a descriptor
+//   fast_mask_kernel        FAST segment test on LDS-staged tiles -> 1 bit per pixel, and per image
+//                           row the number of corners / of corners that get a descriptor
 //   rowscan_kernel          per frame: exclusive prefix over the row counts
 //   emit_kernel             ordered expansion of the bit mask into (x, y) lists (ballot-free
 //                           popcount + wave prefix; ascending y then x by construction)
@@ -502,7 +502,8 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
 // parallelism than the prefetch bought.)
 __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
                                                         int W, uint32_t* __restrict__ mask, int MW,
-                                                        int aligned, int ntc, int ntr)
+                                                        int aligned, int ntc, int ntr,
+                                                        unsigned long long* __restrict__ rowcnt)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH + 4];             // 10352 B (+ the last row's right halo)
     __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
@@ -538,13 +539,27 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
     fast_eval_tile(tile32, mtile, lists[wave][0], lists[wave][1], lane, wave, x0, y0, H, W);
     __syncthreads();
 
-    // write the tile's mask words (FT_H rows x 8 words)
+    // write the tile's mask words (FT_H rows x 8 words) and add this tile's share to the row totals:
+    // (corners, corners that get a descriptor = >= 16 px from every edge, reference src/orb.cpp:156)
+    // as the two halves of one 64-bit add.  rowcnt is zeroed before the launch.
     const int row = threadIdx.x >> 3, wq = threadIdx.x & 7;
     const int y = y0 + row, wi = (x0 >> 5) + wq;
-    if (y < H && wi < MW) mfr[(size_t)y * MW + wi] = mtile[threadIdx.x];
+    uint32_t packed = 0;
+    if (y < H && wi < MW) {
+        const uint32_t m = mtile[threadIdx.x];
+        mfr[(size_t)y * MW + wi] = m;
+        const bool yv = (y - 16 >= 0) && (y + 16 < H);
+        packed = (uint32_t)__popc(m) | ((yv ? (uint32_t)__popc(m & desc_column_bits(wi, W)) : 0u) << 16);
+    }
+    packed += __shfl_xor(packed, 1);
+    packed += __shfl_xor(packed, 2);
+    packed += __shfl_xor(packed, 4);          // sum over the row's 8 words (at most 256 per half)
+    if (wq == 0 && y < H && packed != 0u)
+        atomicAdd(rowcnt + (size_t)f * H + y,
+                  (unsigned long long)(packed & 0xFFFFu) | ((unsigned long long)(packed >> 16) << 32));
 }
 
-void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
+void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStream_t s)
 {
     const int MW = mask_words(fs.W);
     const int ntc = (fs.W + FT_W - 1) / FT_W, ntr = (fs.H + FT_H - 1) / FT_H;
@@ -552,7 +567,8 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
     int aligned = 1;
     if ((fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0) aligned = 16;
     else if ((fs.W & 3) == 0 && ((uintptr_t)fs.gray & 3) == 0) aligned = 4;
-    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned, ntc, ntr);
+    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned, ntc, ntr,
+                       reinterpret_cast<unsigned long long*>(rowcnt));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,33 +577,6 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s)
 // row each lane owns 32 consecutive pixels.  A keypoint "has a descriptor" iff it is >= 16 px from
 // every edge (reference src/orb.cpp:156); its descriptor row is its rank among those.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rowcount_kernel(const uint32_t* __restrict__ mask, int H, int W,
-                                                       int MW, long nrows, int2* __restrict__ rowcnt)
-{
-    const long row = (long)blockIdx.x * 4 + wave_id();  // frame * H + y
-    if (row >= nrows) return;
-    const int lane = lane_id();
-    const int y = (int)(row % H);
-    const bool yv = (y - 16 >= 0) && (y + 16 < H);
-    const uint32_t* mrow = mask + (size_t)row * MW;
-    int c = 0, cv = 0;
-    for (int w = lane; w < MW; w += 64) {
-        uint32_t bits = mrow[w];
-        c += __popc(bits);
-        if (yv) cv += __popc(bits & desc_column_bits(w, W));
-    }
-    c = wave_sum(c);
-    cv = wave_sum(cv);
-    if (lane == 0) rowcnt[row] = make_int2(c, cv);
-}
-
-void launch_rowcount(const FrameSet& fs, const uint32_t* mask, int2* rowcnt, hipStream_t s)
-{
-    long nrows = (long)fs.frames * fs.H;
-    hipLaunchKernelGGL(rowcount_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, mask, fs.H,
-                       fs.W, mask_words(fs.W), nrows, rowcnt);
-}
-
 __global__ __launch_bounds__(256) void rowscan_kernel(const int2* __restrict__ rowcnt, int H,
                                                       int2* __restrict__ rowoff,
                                                       int32_t* __restrict__ counts)

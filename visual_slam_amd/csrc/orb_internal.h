@@ -26,8 +26,8 @@ struct ExtractBuffers {
 void launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long npix, hipStream_t s);
 void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint32_t seed, int cell,
                   int density_thr, hipStream_t s);
-void launch_fast_mask(const FrameSet& fs, uint32_t* mask, hipStream_t s);
-void launch_rowcount(const FrameSet& fs, const uint32_t* mask, int2* rowcnt, hipStream_t s);
+// Also accumulates rowcnt[frame][y] = (corners, corners with a descriptor); rowcnt must be zero.
+void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStream_t s);
 void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_t* counts, hipStream_t s);
 void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
                  int cap, int2* kpxy, int32_t* kpslot, hipStream_t s);
