@@ -1048,6 +1048,17 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
             t2y[r] = reinterpret_cast<const double2*>(rot) + ((int)(int8_t)(q >> 24) + 15);
         }
         const double kd = (double)((lane < 31 ? lane : 30) - 15);
+        // rounds >= ROT_TABLE_ROUNDS multiply directly (balances the LDS and vector pipes)
+        constexpr int ROT_TABLE_ROUNDS = 2;
+        double dpx1[4], dpy1[4], dpx2[4], dpy2[4];
+#pragma unroll
+        for (int r = ROT_TABLE_ROUNDS; r < 4; ++r) {
+            const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
+            dpx1[r] = (double)(int8_t)(q & 255u);
+            dpy1[r] = (double)(int8_t)((q >> 8) & 255u);
+            dpx2[r] = (double)(int8_t)((q >> 16) & 255u);
+            dpy2[r] = (double)(int8_t)(q >> 24);
+        }
         uint32_t regs[9];
         int j = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -1090,11 +1101,19 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
                 asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my));   // vector copies: scalar operands halve the add rate
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double2 e1x = *t1x[r], e1y = *t1y[r], e2x = *t2x[r], e2y = *t2y[r];
-                    const float x1r = (float)(e1x.x - e1y.y);     // px1 * c - py1 * s
-                    const float y1r = (float)(e1x.y + e1y.x);     // px1 * s + py1 * c
-                    const float x2r = (float)(e2x.x - e2y.y);
-                    const float y2r = (float)(e2x.y + e2y.x);
+                    float x1r, y1r, x2r, y2r;
+                    if (r < ROT_TABLE_ROUNDS) {
+                        const double2 e1x = *t1x[r], e1y = *t1y[r], e2x = *t2x[r], e2y = *t2y[r];
+                        x1r = (float)(e1x.x - e1y.y);     // px1 * c - py1 * s
+                        y1r = (float)(e1x.y + e1y.x);     // px1 * s + py1 * c
+                        x2r = (float)(e2x.x - e2y.y);
+                        y2r = (float)(e2x.y + e2y.x);
+                    } else {
+                        x1r = (float)(dpx1[r] * cj - dpy1[r] * sn);
+                        y1r = (float)(dpx1[r] * sn + dpy1[r] * cj);
+                        x2r = (float)(dpx2[r] * cj - dpy2[r] * sn);
+                        y2r = (float)(dpx2[r] * sn + dpy2[r] * cj);
+                    }
                     const uint32_t ax = __float_as_uint((cx + x1r) + mx);
                     const uint32_t ay = __float_as_uint((cy + y1r) + my);
                     const uint32_t bx = __float_as_uint((cx + x2r) + mx);
