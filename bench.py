@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--cap", type=int, default=0, help="keypoint capacity per frame (0 = by preset)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-kernel HIP events")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="frame ranges per step whose extraction / matching are pipelined on two streams (1 = off)")
     ap.add_argument("--matcher", default="matrix", choices=["matrix", "valu"],
                     help="Hamming top-2 kernel family: matrix cores (default) or XOR/popcount on the vector ALUs")
     return ap.parse_args()
@@ -78,7 +80,7 @@ def main():
     F = args.frames
     eng = OrbEngine(local_rank, cap=cap)
     from visual_slam_amd import _lib
-    eng.ctx.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
+    eng.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
     gray = eng.synth_frames(F, H, W, first_frame=rank * F, cell=P["cell"], density=P["density"])
     feat = eng.alloc_features(F)
     matches = eng.alloc_matches(F - 1)
@@ -86,9 +88,14 @@ def main():
     sched = FrameRangeScheduler(eng, rank, world, with_keypoints=True)
 
     def step():
-        eng.extract_batch(gray, out=feat)
-        reqs, rbuf = sched.exchange(feat)
-        eng.match_consecutive(feat, out=matches)
+        if args.chunks > 1:
+            # extraction of frame range k+1 overlaps the matching of range k (second stream)
+            eng.extract_and_match(gray, feat, matches, chunks=args.chunks)
+            reqs, rbuf = sched.exchange(feat)
+        else:
+            eng.extract_batch(gray, out=feat)
+            reqs, rbuf = sched.exchange(feat)
+            eng.match_consecutive(feat, out=matches)
         for r in reqs:
             r.wait()
         if rbuf is not None:
@@ -117,10 +124,13 @@ def main():
     value = world * F * args.steps / dt
 
     # ---- per-kernel timing (HIP events on the launch stream), untimed for `value` ------------
+    # One kernel at a time on one stream (whole batch per launch): a kernel's duration is only
+    # meaningful for a roofline when nothing else shares the chip with it.
     eng.ctx.timing_enable(True)
     eng.ctx.timing_reset()
     for _ in range(max(1, args.profile_steps)):
-        step()
+        eng.extract_batch(gray, out=feat)
+        eng.match_consecutive(feat, out=matches)
     torch.cuda.synchronize()
     timing = eng.ctx.timing_read()
     eng.ctx.timing_enable(False)
@@ -227,7 +237,7 @@ def main():
                                    "consecutive pair" % (W, H, F, int(round(n.mean()))),
                        "frames_per_gpu": F, "keypoints_per_frame": float(n.mean()),
                        "descriptors_per_frame": float(nv.mean()), "capacity_per_frame": cap,
-                       "matcher": args.matcher,
+                       "matcher": args.matcher, "pipelined_frame_ranges": args.chunks,
                        "parallelism": "contiguous frame ranges, %d rank(s), RCCL send/recv of the seam frame"
                                       % world},
             "roofline": rooflines.get(dominant),

@@ -68,6 +68,33 @@ def test_extract_batch_and_consecutive_matches(eng):
         assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
 
 
+@pytest.mark.parametrize("frames,chunks", [(7, 3), (5, 5), (2, 4), (1, 4), (9, 2)])
+def test_pipelined_extract_and_match_equals_separate_calls(eng, frames, chunks):
+    """Two-stream pipeline over frame ranges: same features, same matches for every pair, including
+    the pairs that join two ranges; run twice so buffers reused across calls are covered."""
+    import torch
+    H, W = 120, 168
+    a = np.stack([synth.synth_frame(H, W, 40 + f, cell=12) for f in range(frames)])
+    g = torch.from_numpy(a).to(eng.device)
+    ref_f = eng.extract_batch(g)
+    ref_m = eng.match_consecutive(ref_f)
+    eng.sync()
+    for _ in range(2):
+        f = eng.alloc_features(frames)
+        m = eng.alloc_matches(frames - 1)
+        m.idx.fill_(-7); m.dist.fill_(-7); m.good.fill_(9)
+        eng.extract_and_match(g, f, m, chunks=chunks)
+        torch.cuda.synchronize()
+        assert torch.equal(f.counts, ref_f.counts)
+        for i in range(frames):
+            n, nv = (int(v) for v in ref_f.counts[i].tolist())
+            assert torch.equal(f.kp7[i, :n], ref_f.kp7[i, :n]) and torch.equal(f.desc[i, :nv], ref_f.desc[i, :nv])
+            if i:
+                assert torch.equal(m.idx[i - 1, :nv], ref_m.idx[i - 1, :nv])
+                assert torch.equal(m.dist[i - 1, :nv], ref_m.dist[i - 1, :nv])
+                assert torch.equal(m.good[i - 1, :nv], ref_m.good[i - 1, :nv])
+
+
 def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     import torch
     from visual_slam_amd.engine import OrbEngine

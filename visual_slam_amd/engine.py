@@ -31,6 +31,12 @@ class BatchFeatures:
                 self.valid_idx[f, :nv].cpu().numpy())
 
 
+    def view(self, a, b):
+        """Frames [a, b) as views (no copies)."""
+        return BatchFeatures(kp7=self.kp7[a:b], desc=self.desc[a:b], valid_idx=self.valid_idx[a:b],
+                             counts=self.counts[a:b], cap=self.cap)
+
+
 @dataclass
 class BatchMatches:
     """Top-2 neighbours for a list of frame pairs (all on the GPU)."""
@@ -42,6 +48,10 @@ class BatchMatches:
     def pair(self, p, nq):
         return (self.idx[p, :nq].cpu().numpy(), self.dist[p, :nq].cpu().numpy(),
                 self.good[p, :nq].cpu().numpy())
+
+    def view(self, a, b):
+        """Pairs [a, b) as views (no copies)."""
+        return BatchMatches(idx=self.idx[a:b], dist=self.dist[a:b], good=self.good[a:b], cap=self.cap)
 
 
 class OrbEngine:
@@ -56,6 +66,9 @@ class OrbEngine:
         torch.cuda.set_device(self.device)
         self.ctx = _lib.Context(device)
         self.bind_stream()
+        self._match_ctx = None        # second context + stream, created by extract_and_match()
+        self._match_stream = None
+        self._matcher = _lib.MATCHER_MATRIX
 
     def bind_stream(self, stream=None):
         """Run the library's kernels on a torch stream (default: the current one), so that tensor
@@ -66,6 +79,15 @@ class OrbEngine:
 
     def sync(self):
         self.ctx.sync()
+        if self._match_ctx is not None:
+            self._match_ctx.sync()
+
+    def set_matcher(self, matcher):
+        """_lib.MATCHER_MATRIX (default) or _lib.MATCHER_VALU, for every matching call of this engine."""
+        self._matcher = matcher
+        self.ctx.set_matcher(matcher)
+        if self._match_ctx is not None:
+            self._match_ctx.set_matcher(matcher)
 
     # -- inputs ---------------------------------------------------------------------------------
     def synth_frames(self, frames, H, W, first_frame=0, seed=synth.DEFAULT_SEED, cell=20, density=0.386):
@@ -117,6 +139,44 @@ class OrbEngine:
             self.ctx.knn2_batch_dev(feat.desc.data_ptr(), feat.counts.data_ptr(), feat.frames, feat.cap, 0,
                                     npairs, out.idx.data_ptr(), out.dist.data_ptr(), out.good.data_ptr())
         return out
+
+    def extract_and_match(self, gray, feat, matches, chunks=4):
+        """extract_batch(gray) + match_consecutive(feat), pipelined: the frames are cut into `chunks`
+        ranges; while range k+1 is extracted on this engine's stream, range k (plus the pair that
+        joins it to range k-1) is matched on a second stream by a second library context.  The
+        extraction kernels are bound by vector-ALU, LDS and load-address work, the matcher by the
+        matrix cores, so the two overlap on the same compute units.  Results are those of the two
+        separate calls.  On return the engine's stream waits for the matching stream."""
+        frames = gray.shape[0]
+        assert feat.frames == frames and matches.idx.shape[0] >= max(frames - 1, 1)
+        chunks = max(1, min(int(chunks), frames))
+        if chunks == 1 or frames < 2:
+            self.extract_batch(gray, out=feat)
+            return self.match_consecutive(feat, out=matches)
+        if self._match_ctx is None:
+            self._match_stream = torch.cuda.Stream(self.device)
+            self._match_ctx = _lib.Context(self.device.index)
+            self._match_ctx.set_stream(self._match_stream.cuda_stream)
+            self._match_ctx.set_matcher(self._matcher)
+            self._chunk_events = []
+        while len(self._chunk_events) < chunks:
+            self._chunk_events.append(torch.cuda.Event())
+        main, side = self.stream, self._match_stream
+        side.wait_stream(main)                      # earlier work on the outputs is ordered first
+        for k in range(chunks):
+            lo, hi = frames * k // chunks, frames * (k + 1) // chunks
+            self.extract_batch(gray[lo:hi], out=feat.view(lo, hi))
+            self._chunk_events[k].record(main)
+            side.wait_event(self._chunk_events[k])
+            q0 = max(lo - 1, 0)                     # the pair (lo, lo - 1) belongs to this range
+            if hi - q0 >= 2:
+                f = feat.view(q0, hi)
+                o = matches.view(q0, hi - 1)
+                self._match_ctx.knn2_batch_dev(f.desc.data_ptr(), f.counts.data_ptr(), f.frames, f.cap, 0,
+                                               f.frames - 1, o.idx.data_ptr(), o.dist.data_ptr(),
+                                               o.good.data_ptr())
+        main.wait_stream(side)
+        return matches
 
     def match_pairs(self, feat, pairs, out=None):
         """Arbitrary (query frame, train frame) pairs inside one batch; pairs: int32 [npairs, 2] on GPU."""
