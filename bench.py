@@ -242,6 +242,8 @@ def main():
                                       % world},
             "roofline": rooflines.get(dominant),
             "roofline_kernel": dominant,
+            "roofline_launches": "whole-batch launches, one kernel at a time (what --chunks 1 runs); the timed "
+                                 "steps pipeline %d frame ranges on two streams" % args.chunks,
             "rooflines": rooflines,
             "cpu_baseline": cpu,
             "gpu_matches_cpu_on_sample": check,
