@@ -191,6 +191,34 @@ def main():
                 rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
 
+    # ---- the same steps with the XOR/popcount matcher on the vector ALUs (reported beside `value`) --
+    valu_alt = None
+    if args.matcher == "matrix" and rank == 0 and world == 1:
+        eng.set_matcher(_lib.MATCHER_VALU)
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence()
+        vdt = (time.perf_counter() - t0) / 3
+        eng.ctx.timing_enable(True)
+        eng.ctx.timing_reset()
+        eng.match_consecutive(feat, out=matches)
+        torch.cuda.synchronize()
+        vms, vl = eng.ctx.timing_read().get("knn2", (0.0, 0))
+        eng.ctx.timing_enable(False)
+        eng.set_matcher(_lib.MATCHER_MATRIX)
+        eng.match_consecutive(feat, out=matches)      # leave the matrix-core results in `matches`
+        torch.cuda.synchronize()
+        valu_alt = {"value": F / vdt, "unit": "frames/s", "ms_per_step": vdt * 1e3}
+        if vl:
+            ach = float(16 * (nv[1:] * nv[:-1]).sum()) / (vms / vl / 1e3) / 1e12
+            valu_alt["knn2_roofline"] = {"bound": "int_valu", "achieved": ach, "peak": INT_VALU_PEAK_TOPS,
+                                         "unit": "Tintop/s", "frac": ach / INT_VALU_PEAK_TOPS, "avg_ms": vms / vl,
+                                         "peak_measured_mix": INT_VALU_MEASURED_MIX_TOPS,
+                                         "frac_of_measured_mix": ach / INT_VALU_MEASURED_MIX_TOPS}
+
     # ---- CPU baseline + result check on a bounded sample (rank 0, N = 1) ------------------------
     cpu = None
     check = None
@@ -245,6 +273,7 @@ def main():
             "roofline_launches": "whole-batch launches, one kernel at a time (what --chunks 1 runs); the timed "
                                  "steps pipeline %d frame ranges on two streams" % args.chunks,
             "rooflines": rooflines,
+            "valu_matcher": valu_alt,
             "cpu_baseline": cpu,
             "gpu_matches_cpu_on_sample": check,
         }
