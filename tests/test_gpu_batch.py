@@ -242,6 +242,35 @@ def test_full_size_1080p_batch_properties(eng):
     assert np.array_equal(bits(kp), bits(ekp)) and np.array_equal(desc, edesc) and np.array_equal(vidx, evidx)
 
 
+def test_4k_frames_pipelined_against_oracle():
+    """3840x2160 frames (~20k keypoints each, capacity 32768) through the pipelined batch path: every
+    frame's features and every consecutive pair's top-2 equal the CPU restatement."""
+    import torch
+    from visual_slam_amd.engine import OrbEngine
+    P = synth.PRESETS["4k"]
+    e = OrbEngine(0, cap=32768)
+    F = 3
+    gray = e.synth_frames(F, P["H"], P["W"], first_frame=7, cell=P["cell"], density=P["density"])
+    feat = e.alloc_features(F)
+    m = e.alloc_matches(F - 1)
+    e.extract_and_match(gray, feat, m, chunks=2)
+    torch.cuda.synchronize()
+    host = gray.cpu().numpy()
+    ex = [oracle.c.extract_gray(host[i]) for i in range(F)]
+    for i in range(F):
+        kp, desc, vidx = feat.frame(i)
+        assert 15000 < len(kp) < 25000
+        assert np.array_equal(bits(kp), bits(ex[i][0])) and np.array_equal(desc, ex[i][1])
+        assert np.array_equal(vidx, ex[i][2])
+        if i:
+            eidx, edist = oracle.c.knn2(ex[i][1], ex[i - 1][1])
+            idx, dist, good = m.pair(i - 1, len(desc))
+            assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+            want = np.zeros(len(desc), np.uint8)
+            want[oracle.c.ratio_filter(eidx, edist)[0]] = 1
+            assert np.array_equal(good, want)
+
+
 def test_device_libm_parity_gate_orientation(gctx):
     """Orientation goes through double atan2 on the device and through glibc in the reference; the
     float angle must agree bit for bit.  ~2.8 M keypoints on images with strong gradients."""
