@@ -176,3 +176,41 @@ def test_extract_on_widths_that_exercise_every_staging_path(gctx, H, W):
     widths around the 256-pixel tile edge and wider than one wave's 64 mask words are included."""
     img = make_test_image(H, W, 1000 + W)
     assert_extract_equal(gctx.extract_gray(img), oracle.c.extract_gray(img))
+
+
+def test_extract_fuzz_shapes_and_textures(gctx):
+    """Random sizes (tiny, odd widths, widths around the tile and chunk sizes) and textures (sparse
+    specks, dense noise with thousands of corners, saturated blocks): GPU == CPU restatement."""
+    rng = np.random.default_rng(2024)
+    shapes = [(7, 7), (8, 9), (6, 40), (33, 7), (31, 31), (32, 36), (37, 64), (48, 255), (49, 256), (50, 257),
+              (64, 260), (65, 511), (40, 513), (97, 101), (130, 300), (33, 1028)]
+    shapes += [(int(rng.integers(7, 160)), int(rng.integers(7, 700))) for _ in range(14)]
+    for k, (H, W) in enumerate(shapes):
+        kind = k % 3
+        if kind == 0:
+            img = make_test_image(H, W, 500 + k)
+        elif kind == 1:
+            img = rng.integers(0, 256, (H, W), dtype=np.uint8)                     # dense noise
+        else:
+            img = (rng.integers(0, 2, (H // 3 + 1, W // 3 + 1)) * 255).astype(np.uint8)
+            img = np.kron(img, np.ones((3, 3), np.uint8))[:H, :W].copy()           # saturated 3x3 blocks
+        got = gctx.extract_gray(img)
+        exp = oracle.c.extract_gray(img)
+        assert_extract_equal(got, exp)
+
+
+def test_knn2_fuzz_sizes_around_tile_edges(gctx, matcher):
+    """Row counts around the 32-row tiles, the 64-lane waves and the 256-query blocks."""
+    rng = np.random.default_rng(99)
+    sizes = [0, 1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513]
+    for k in range(40):
+        nq = int(rng.choice(sizes[1:]))
+        nt = int(rng.choice(sizes))
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nt > 3 and k % 2:
+            t[rng.integers(0, nt, nt // 3)] = t[0]          # heavy duplication: index tie-breaks
+            q[: max(1, nq // 4)] = t[0]
+        idx, dist = gctx.knn2(q, t)
+        eidx, edist = oracle.c.knn2(q, t)
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist), (nq, nt)
