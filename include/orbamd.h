@@ -182,6 +182,19 @@ int orbamd_knn2_batch_dev(orbamd_ctx* ctx, const uint8_t* d_desc, const int32_t*
                           int frames, int cap, const int32_t* d_pairs, int npairs,
                           int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
 
+/* The ratio-filter loop (reference views.py:163-171) for every pair of a batch matched by
+ * orbamd_knn2_batch_dev, on the device: per pair, in ascending query order, the kept matches as
+ * three lists with the reference's contents -- m1.queryIdx, m2.trainIdx (sic, views.py:170) and
+ * m1.trainIdx.  d_pairs / frame numbering as in orbamd_knn2_batch_dev (the query frame's descriptor
+ * count comes from d_counts).
+ *   d_good_q, d_good_t2, d_good_t1  int32 [npairs, cap]   first d_kept[p] entries of row p are valid
+ *   d_kept                          int32 [npairs]        number kept; -1 when some query of the pair
+ *                                   has fewer than two neighbours (the reference's loop raises there) */
+int orbamd_ratio_filter_batch_dev(orbamd_ctx* ctx, const int32_t* d_idx, const uint8_t* d_good,
+                                  const int32_t* d_counts, int frames, int cap, const int32_t* d_pairs,
+                                  int npairs, int32_t* d_good_q, int32_t* d_good_t2, int32_t* d_good_t1,
+                                  int32_t* d_kept);
+
 /* One frame pair whose two frames live in different frame-strided buffers with device-side
  * counts: query frame `qframe` of (d_qdesc, d_qcounts) against train frame `tframe` of
  * (d_tdesc, d_tcounts), both with per-frame capacity `cap`.  This is the pair that spans two

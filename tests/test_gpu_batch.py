@@ -95,6 +95,41 @@ def test_pipelined_extract_and_match_equals_separate_calls(eng, frames, chunks):
                 assert torch.equal(m.good[i - 1, :nv], ref_m.good[i - 1, :nv])
 
 
+def test_batch_ratio_filter_lists_match_oracle(eng):
+    """Device-side ratio-filter lists for consecutive pairs and for an explicit pair list."""
+    import torch
+    H, W = 160, 208
+    a = np.stack([synth.synth_frame(H, W, 70 + f, cell=12) for f in range(4)])
+    feat = eng.extract_batch(torch.from_numpy(a).to(eng.device))
+    m = eng.match_consecutive(feat)
+    gq, gt2, gt1, kept = eng.good_matches(feat, m)
+    pairs = torch.tensor([[3, 0], [1, 1]], dtype=torch.int32, device=eng.device)
+    mp = eng.match_pairs(feat, pairs)
+    pq, pt2, pt1, pkept = eng.good_matches(feat, mp, pairs)
+    eng.sync()
+    descs = [oracle.c.extract_gray(a[i])[1] for i in range(4)]
+
+    def check(qd, td, row_q, row_t2, row_t1, k):
+        eidx, edist = oracle.c.knn2(qd, td)
+        eq, e2, e1 = oracle.c.ratio_filter(eidx, edist)
+        assert k == len(eq) and k > 0
+        assert np.array_equal(row_q[:k], eq) and np.array_equal(row_t2[:k], e2) and np.array_equal(row_t1[:k], e1)
+
+    for p in range(3):
+        check(descs[p + 1], descs[p], gq[p].cpu().numpy(), gt2[p].cpu().numpy(), gt1[p].cpu().numpy(), int(kept[p]))
+    check(descs[3], descs[0], pq[0].cpu().numpy(), pt2[0].cpu().numpy(), pt1[0].cpu().numpy(), int(pkept[0]))
+    check(descs[1], descs[1], pq[1].cpu().numpy(), pt2[1].cpu().numpy(), pt1[1].cpu().numpy(), int(pkept[1]))
+    # a pair whose train frame has a single descriptor: the reference's loop cannot unpack two neighbours
+    desc = torch.zeros((2, feat.cap, 32), dtype=torch.uint8, device=eng.device)
+    counts = torch.tensor([[1, 1], [5, 5]], dtype=torch.int32, device=eng.device)
+    from visual_slam_amd.engine import BatchFeatures
+    f2 = BatchFeatures(kp7=None, desc=desc, valid_idx=None, counts=counts, cap=feat.cap)
+    m2 = eng.match_consecutive(f2)
+    _, _, _, k2 = eng.good_matches(f2, m2)
+    eng.sync()
+    assert int(k2[0]) == -1
+
+
 def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     import torch
     from visual_slam_amd.engine import OrbEngine

@@ -51,6 +51,7 @@ SIGNATURES = {
     "orbamd_bgr2gray_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _vp]),
     "orbamd_extract_batch_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "orbamd_knn2_batch_dev": (_int, [_c_ctx, _vp, _vp, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "orbamd_ratio_filter_batch_dev": (_int, [_c_ctx, _vp, _vp, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "orbamd_knn2_cross_dev": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "orbamd_knn2_dev": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp]),
 }
@@ -290,6 +291,12 @@ class Context:
     def knn2_batch_dev(self, d_desc, d_counts, frames, cap, d_pairs, npairs, d_idx, d_dist, d_good):
         self._chk(lib().orbamd_knn2_batch_dev(self._h, _vp(d_desc), _vp(d_counts), frames, cap, _vp(d_pairs or 0),
                                               npairs, _vp(d_idx), _vp(d_dist), _vp(d_good or 0)), "knn2_batch_dev")
+
+    def ratio_filter_batch_dev(self, d_idx, d_good, d_counts, frames, cap, d_pairs, npairs, d_good_q, d_good_t2,
+                               d_good_t1, d_kept):
+        self._chk(lib().orbamd_ratio_filter_batch_dev(self._h, _vp(d_idx), _vp(d_good), _vp(d_counts), frames, cap,
+                                                      _vp(d_pairs or 0), npairs, _vp(d_good_q), _vp(d_good_t2),
+                                                      _vp(d_good_t1), _vp(d_kept)), "ratio_filter_batch_dev")
 
     def knn2_cross_dev(self, d_qdesc, d_qcounts, qframe, d_tdesc, d_tcounts, tframe, cap, d_idx, d_dist, d_good=0):
         self._chk(lib().orbamd_knn2_cross_dev(self._h, _vp(d_qdesc), _vp(d_qcounts), qframe, _vp(d_tdesc),

@@ -724,6 +724,25 @@ int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d
     return run_knn2(c, a);
 }
 
+int orbamd_ratio_filter_batch_dev(orbamd_ctx* c, const int32_t* d_idx, const uint8_t* d_good,
+                                  const int32_t* d_counts, int frames, int cap, const int32_t* d_pairs,
+                                  int npairs, int32_t* d_good_q, int32_t* d_good_t2, int32_t* d_good_t1,
+                                  int32_t* d_kept)
+{
+    CHK(enter(c));
+    if (!d_idx || !d_good || !d_counts || !d_good_q || !d_good_t2 || !d_good_t1 || !d_kept || frames <= 0 ||
+        cap <= 0 || npairs < 0 || npairs > 65535)
+        return ORBAMD_E_BADARG;
+    if (!d_pairs && npairs > frames - 1) return ORBAMD_E_BADARG;
+    if (npairs == 0) return ORBAMD_OK;
+    {
+        Timed t(c, ORBAMD_K_RATIO);
+        launch_ratio_compact_batch(d_idx, d_good, d_counts, d_pairs, npairs, cap, d_good_q, d_good_t2, d_good_t1,
+                                   d_kept, c->stream);
+    }
+    return post_launch(c, "ratio_compact_batch_kernel");
+}
+
 int orbamd_knn2_cross_dev(orbamd_ctx* c, const uint8_t* d_qdesc, const int32_t* d_qcounts, int qframe,
                           const uint8_t* d_tdesc, const int32_t* d_tcounts, int tframe, int cap, int32_t* d_idx,
                           int32_t* d_dist, uint8_t* d_good)

@@ -1650,6 +1650,62 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int32_t* __re
     if (threadIdx.x == 0) count[0] = bad ? -1 : carry;
 }
 
+// The same compaction for every pair of a batch: one workgroup per pair, flags from the matcher.
+__global__ __launch_bounds__(1024) void ratio_compact_batch_kernel(const int32_t* __restrict__ idx,
+                                                                   const uint8_t* __restrict__ good,
+                                                                   const int32_t* __restrict__ qcounts,
+                                                                   const int32_t* __restrict__ pairs, int cap,
+                                                                   int32_t* __restrict__ good_q,
+                                                                   int32_t* __restrict__ good_t2,
+                                                                   int32_t* __restrict__ good_t1,
+                                                                   int32_t* __restrict__ kept)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    __shared__ int bad;
+    const int pair = blockIdx.x;
+    const int qf = pairs ? pairs[2 * pair] : pair + 1;
+    int nq = qcounts[2 * qf + 1];
+    nq = nq < cap ? nq : cap;
+    if (threadIdx.x == 0) { carry = 0; bad = 0; }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const size_t row0 = (size_t)pair * cap;
+    for (int i0 = 0; i0 < nq; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        int keep = 0;
+        int2 id = make_int2(0, 0);
+        if (i < nq) {
+            id = reinterpret_cast<const int2*>(idx)[row0 + i];
+            if (id.x < 0 || id.y < 0) bad = 1;
+            else keep = good[row0 + i] != 0;
+        }
+        const int ik = wave_incl_scan(keep, lane);
+        if (lane == 63) wsum[wave] = ik;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (keep) {
+            const size_t o = row0 + base + ik - 1;
+            good_q[o] = i;
+            good_t2[o] = id.y;
+            good_t1[o] = id.x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + ik;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kept[pair] = bad ? -1 : carry;
+}
+
+void launch_ratio_compact_batch(const int32_t* idx, const uint8_t* good, const int32_t* qcounts,
+                                const int32_t* pairs, int npairs, int cap, int32_t* good_q, int32_t* good_t2,
+                                int32_t* good_t1, int32_t* kept, hipStream_t s)
+{
+    hipLaunchKernelGGL(ratio_compact_batch_kernel, dim3(npairs), dim3(1024), 0, s, idx, good, qcounts, pairs, cap,
+                       good_q, good_t2, good_t1, kept);
+}
+
 void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32_t* good_q,
                           int32_t* good_t2, int32_t* good_t1, int32_t* count, hipStream_t s)
 {

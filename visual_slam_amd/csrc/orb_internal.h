@@ -69,6 +69,11 @@ void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_
 // query has fewer than two neighbours.
 void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32_t* good_q,
                           int32_t* good_t2, int32_t* good_t1, int32_t* count, hipStream_t s);
+// Per pair of a batch: ordered lists of the queries whose flag in good[pair][*] is set; kept[pair] =
+// their number, or -1 when a query of the pair has fewer than two neighbours.
+void launch_ratio_compact_batch(const int32_t* idx, const uint8_t* good, const int32_t* qcounts,
+                                const int32_t* pairs, int npairs, int cap, int32_t* good_q, int32_t* good_t2,
+                                int32_t* good_t1, int32_t* kept, hipStream_t s);
 void launch_knn2(const Knn2Args& a, hipStream_t s);
 // FP4 image of descriptor rows: slot s takes frame (pairs ? pairs[2 s + side] : frame0 + s) of
 // `desc` (rows per frame = cap, row counts from counts[2 f + 1]; or n_fixed rows when counts == NULL)

@@ -178,6 +178,23 @@ class OrbEngine:
         main.wait_stream(side)
         return matches
 
+    def good_matches(self, feat, matches, pairs=None):
+        """The reference's ratio-filter lists (views.py:163-171) for every pair of `matches`, built on
+        the GPU: (good_q, good_t2, good_t1) int32 [npairs, cap] and kept int32 [npairs]; row p holds
+        kept[p] entries (m1.queryIdx, m2.trainIdx, m1.trainIdx), kept[p] = -1 if a query of the pair
+        has fewer than two neighbours.  `pairs` as given to match_pairs, None for match_consecutive."""
+        npairs = pairs.shape[0] if pairs is not None else feat.frames - 1
+        cap, dev = matches.cap, self.device
+        gq = torch.empty((max(npairs, 1), cap), dtype=torch.int32, device=dev)
+        gt2 = torch.empty_like(gq)
+        gt1 = torch.empty_like(gq)
+        kept = torch.zeros((max(npairs, 1),), dtype=torch.int32, device=dev)
+        if npairs > 0:
+            self.ctx.ratio_filter_batch_dev(matches.idx.data_ptr(), matches.good.data_ptr(), feat.counts.data_ptr(),
+                                            feat.frames, cap, pairs.data_ptr() if pairs is not None else 0, npairs,
+                                            gq.data_ptr(), gt2.data_ptr(), gt1.data_ptr(), kept.data_ptr())
+        return gq, gt2, gt1, kept
+
     def match_pairs(self, feat, pairs, out=None):
         """Arbitrary (query frame, train frame) pairs inside one batch; pairs: int32 [npairs, 2] on GPU."""
         npairs = pairs.shape[0]
