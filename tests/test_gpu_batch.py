@@ -130,6 +130,42 @@ def test_batch_ratio_filter_lists_match_oracle(eng):
     assert int(k2[0]) == -1
 
 
+@pytest.mark.parametrize("bgr", [False, True])
+def test_host_frame_stager_equals_whole_batch(eng, bgr):
+    """Frames fed from host memory in chunks of 4 (10 frames: two full chunks and a short one): same
+    features per frame and the same matches for every consecutive pair, also across chunk seams."""
+    import torch
+    from visual_slam_amd.staging import HostFrameStager
+    H, W, F = 96, 144, 10
+    gray = np.stack([synth.synth_frame(H, W, 300 + f, cell=12) for f in range(F)])
+    if bgr:
+        rng = np.random.default_rng(4)
+        frames = rng.integers(0, 256, (F, H, W, 3), dtype=np.uint8)
+        frames[..., 1] = gray                       # keep the blobs visible after the conversion
+        gray_ref = np.stack([oracle.c.bgr2gray(f) for f in frames])
+    else:
+        frames, gray_ref = gray, gray
+    ex = [oracle.c.extract_gray(g) for g in gray_ref]
+    st = HostFrameStager(eng, H, W, chunk=4, bgr=bgr)
+    seen = 0
+    for ch in st.run(iter(frames)):
+        torch.cuda.synchronize()
+        assert ch.first == seen
+        for i in range(ch.frames):
+            f = ch.first + i
+            kp, desc, vidx = ch.features.frame(i)
+            assert np.array_equal(bits(kp), bits(ex[f][0])) and np.array_equal(desc, ex[f][1])
+            assert np.array_equal(vidx, ex[f][2])
+            idx, dist, good = ch.matches.pair(i, len(desc))
+            if f == 0:
+                assert (idx == -1).all()
+            else:
+                eidx, edist = oracle.c.knn2(ex[f][1], ex[f - 1][1])
+                assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        seen += ch.frames
+    assert seen == F
+
+
 def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     import torch
     from visual_slam_amd.engine import OrbEngine
