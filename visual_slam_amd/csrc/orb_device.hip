@@ -468,6 +468,20 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
         }
     }
 
+    // Sparse tile (at most 16 listed dwords = 64 pixels): skip the compass screen and give every
+    // pixel of the listed dwords straight to the exact test, one batch.
+    if (countA <= 16) {
+        if (countA > 0) {
+            const int n = 4 * countA;
+            if (lane < n) {
+                const uint32_t e = listA[lane >> 2];
+                listB[lane] = (uint16_t)(((e >> 6) << 8) | (4 * (e & 63u) + (uint32_t)(lane & 3)));
+            }
+            fast_exact_batch(tile, mtile, listB, 0, n, lane, r0, x0, y0, H, W);
+        }
+        return;
+    }
+
     // ---- phase 2a: compass screen on the listed dwords, one per lane; 2b whenever B holds 64 ----
     for (int i0 = 0; i0 < countA; i0 += 64) {
         const int i = i0 + lane;
