@@ -9,9 +9,14 @@
 //   emit_kernel             ordered expansion of the bit mask into (x, y) lists (ballot-free
 //                           popcount + wave prefix; ascending y then x by construction)
 //   slots_kernel            descriptor row numbers for caller-supplied keypoint lists
-//   orient_describe_kernel  one wavefront per batch of keypoints: 31x31 moments, atan2, steered BRIEF-256
-//   knn2_kernel             Hamming top-2, one query per lane, train rows broadcast
+//   orient_describe_kernel  256 keypoints per workgroup in x order, 64 per wavefront: 31x31 moments
+//                           (four keypoints per step), atan2 / cos / sin once per lane, steered
+//                           BRIEF-256 from an LDS-staged window
+//   expand_fp4_kernel       descriptor bits -> +-1 FP4 operand image for the matrix-core matcher
+//   knn2_mfma_kernel        Hamming top-2 on the matrix cores (default)
+//   knn2_kernel             Hamming top-2 by XOR + popcount, one query per lane, train rows broadcast
 //   knn2_merge_kernel       merges train-axis partial results
+//   ratio_compact_kernel, ratio_compact_batch_kernel   ordered lists of the matches that pass the ratio test
 //
 // Floating point on the parity path is compiled without contraction: the reference computes
 // x*c - y*s as two rounded products and one rounded difference (reference src/orb.cpp:195-199).
@@ -57,13 +62,6 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
         int t = __shfl_up(v, o);
         if (lane >= o) v += t;
     }
-    return v;
-}
-
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
@@ -722,9 +720,10 @@ void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_
 // point is rotated with double cos/sin (two rounded products, one rounded sum), narrowed to
 // float, added to the float centre, rounded half-to-even; samples outside the image read 0.
 //
-// Work decomposition: one wavefront owns a batch of KPW consecutive keypoints and runs three
-// phases.  A: for each keypoint in turn, all 64 lanes sum its patch (wave-wide, DPP reduction) and
-// the totals are parked in the lane whose number is the keypoint's position in the batch.
+// Work decomposition: a workgroup owns 4 * KPW consecutive keypoints and hands them to its four
+// wavefronts in x order (see the kernel); each wavefront runs three phases over its KPW keypoints.
+// A: patch moments, four keypoints per step with 16 lanes each (DPP row reduction); the totals are
+// parked in the lane whose number is the keypoint's position in the batch.
 // B: every lane computes atan2 / cos / sin for ITS keypoint -- the double-precision library calls
 // cost thousands of cycles, so they run once per batch with 64 keypoints side by side instead of
 // once per keypoint with 64 lanes doing the same thing.  C: for each keypoint in turn, cos / sin /
