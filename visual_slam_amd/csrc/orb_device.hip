@@ -1424,14 +1424,13 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint8_t* __restri
 // sorted {m1, a, b}, the new pair is (s1, max(s2, m2)) because m2 <= m1 <= s1.
 // max(x, y) is written med3(x, y, +inf): the median intrinsic needs no NaN canonicalisation of
 // its inputs, which a float max of raw accumulator registers would get.
-// v_max3_f32 has no builtin.  The asm statement also names s2 as an input it does not use: the
-// compiler inserts the wait states between a matrix instruction and the first vector instruction
-// that reads its result only for instructions it emitted itself, so the asm must stay behind the
-// med3 that reads the same two accumulator registers.
+// The two-step fmaxf is selected as one v_max3_f32.  (No inline asm here: the compiler inserts the wait
+// states between a matrix instruction and the first vector instruction that reads its result only for
+// instructions it emitted itself; an asm v_max3_f32 in this place read stale accumulators.)
 __device__ __forceinline__ void top2_insert2_f32(float& m1, float& m2, float a, float b, float pinf)
 {
     const float s2 = __builtin_amdgcn_fmed3f(m1, a, b);
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(m1), "v"(a), "v"(b), "v"(s2));
+    m1 = __builtin_fmaxf(__builtin_fmaxf(m1, a), b);
     m2 = __builtin_amdgcn_fmed3f(s2, m2, pinf);
 }
 
