@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t xcd_contiguous_item()
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + pos;
 }
 
+// v + (v of the lane a DPP control selects); lanes the control leaves without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
 #pragma unroll
@@ -209,29 +216,31 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 // the cheap screen used here; it is implied by the reference's own four-point pre-test (:65-68),
 // so screening with it cannot lose a corner.
 //
-// Tile: 256 x 32 outputs per 256-thread workgroup, staged in LDS (3-row halo, one dword of column
-// halo each side, filled by aligned dword reads).  A wave walks 8 rows; a lane owns one dword = 4
-// horizontally adjacent pixels and keeps a 7-row register window (three LDS dword reads per row).
+// Tile: 256 x 64 outputs per 256-thread workgroup, staged in LDS with a 3-row halo above and below
+// and a 16-byte margin left and right (which holds the 3 halo columns).  A wave owns a strip of 16
+// rows and walks it in two passes of 8; a lane owns one dword = 4 horizontally adjacent pixels.
 //   Phase 1, per dword: v_sad_u8 gives sum |N_k - C_k| over the dword's 4 pixels; a pixel can only
 //     pass the compass screen through (N, S) if that sum and the S sum are both >= 20, likewise
 //     (E, W).  One max/min/compare decides for 4 pixels; passing dwords are pushed to list A.
 //   Phase 2a, per listed dword (one per lane): the compass screen proper, per byte position with
 //     SDWA byte selects; results are 64-bit lane masks combined on the scalar unit; passing
-//     pixels are pushed to list B.
+//     pixels are pushed to list B.  Skipped when list A is short: its pixels go straight to 2b.
 //   Phase 2b, per listed pixel (one per lane): the full 16-pixel test; hits are OR-ed into the
 //     tile's bit mask in LDS, which is written out coalesced at the end.
 // Lists live in LDS per wave and are filled with mbcnt ranks, so every stage after phase 1 runs
 // with all lanes busy however sparse the corners are.
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_W = 256, FT_H = 32;
-constexpr int FT_PITCH = FT_W / 4 + 4;     // LDS row pitch in dwords: pixel x of a tile row sits at byte
-                                           // 16 + (x - x0); the left halo dword is at byte 12, the right
-                                           // halo dword (byte 272) falls into the next row's unused pad, so
-                                           // the 256-byte body of every row is 16-byte aligned
+constexpr int FT_W = 256, FT_H = 64;
+constexpr int FT_PITCH = FT_W / 4 + 8;     // LDS row pitch in dwords: 16 bytes of left margin, the 256-byte
+                                           // body, 16 bytes of right margin; pixel x of a tile row sits at
+                                           // byte 16 + (x - x0), the halo columns x0 - 3 .. x0 - 1 in bytes
+                                           // 13 .. 15 and x0 + 256 .. x0 + 258 in bytes 272 .. 274
 constexpr int FT_X0 = 4;                   // dword index of pixel x0 within an LDS row
 constexpr int FT_LW = FT_PITCH * 4;        // LDS row pitch in bytes
 constexpr int FT_LH = FT_H + 6;            // LDS rows
 constexpr int FT_ROWS_PER_WAVE = FT_H / 4;
+constexpr int FT_EVAL_ROWS = 8;           // rows of one evaluation pass (bounds list A: 64 entries a row)
+static_assert(FT_ROWS_PER_WAVE % FT_EVAL_ROWS == 0, "a wave's rows are whole evaluation passes");
 
 // Circle offsets in LDS bytes, k = 0 at (0,-3), clockwise (reference src/orb.cpp:43-48).
 __device__ __forceinline__ constexpr int circ_off(int k)
@@ -239,16 +248,6 @@ __device__ __forceinline__ constexpr int circ_off(int k)
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int dy[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
     return dy[k] * FT_LW + dx[k];
-}
-
-__device__ __forceinline__ bool run12(uint32_t m)
-{
-    // m: 16 class bits; true iff bits s..s+11 are all set for some s in 0..4 (no wrap).
-    m &= m >> 1;
-    m &= m >> 2;
-    m &= m >> 4;   // bit i = bits i..i+7 set
-    m &= m >> 4;   // bit i = bits i..i+11 set
-    return (m & 0x1Fu) != 0;
 }
 
 // Lane masks of "byte K of a >= b" (unsigned) and "byte K of a <= b" (signed; b may be negative).
@@ -271,7 +270,9 @@ __device__ __forceinline__ bool run12(uint32_t m)
         cand = (bn_ & bs_) | (be_ & bw_) | (dn_ & ds_) | (de_ & dw_);               \
     }
 
-constexpr int FT_LIST = 512;   // entries per wave and list (flushed before they can overflow)
+constexpr int FT_LIST_A = 576;   // entries of list A per wave (resolved before a pass could overflow it)
+constexpr int FT_LIST_B = 320;   // entries of list B per wave (at most 63 + 4 * 64 are ever held)
+constexpr int FT_SPARSE = 32;   // up to this many listed dwords skip the compass screen
 
 // Push the lanes of `m` (a wave-uniform lane mask) onto a per-wave LDS list.
 __device__ __forceinline__ void list_push(uint16_t* list, int& count, unsigned long long m, int lane,
@@ -287,28 +288,40 @@ __device__ __forceinline__ void list_push(uint16_t* list, int& count, unsigned l
 
 // Phase 2b: exact segment test for list entries [from, from + n), n <= 64, one per lane.
 // Entry = (row within the wave's strip) << 8 | (x within the tile).
+// Every comparison "circle pixel k is brighter / darker" is made for all 64 lanes at once into a
+// 64-bit lane mask (one v_cmp each), and the run test is evaluated on those masks by the scalar
+// unit: a run k = s .. s+11 (s = 0 .. 4) is the core k = 4 .. 11 plus a suffix of k = 0 .. 3 and a
+// prefix of k = 12 .. 15.  Lanes without an entry evaluate entry 0 (in bounds) and are masked out.
+__device__ __forceinline__ unsigned long long run12_lanes(const unsigned long long (&m)[16])
+{
+    const unsigned long long core = m[4] & m[5] & m[6] & m[7] & m[8] & m[9] & m[10] & m[11];
+    if (core == 0ull) return 0ull;
+    const unsigned long long l3 = m[3], l2 = l3 & m[2], l1 = l2 & m[1], l0 = l1 & m[0];
+    const unsigned long long r12 = m[12], r13 = r12 & m[13], r14 = r13 & m[14], r15 = r14 & m[15];
+    return core & (l0 | (l1 & r12) | (l2 & r13) | (l3 & r14) | r15);
+}
+
 __device__ __forceinline__ void fast_exact_batch(const uint8_t* tile, uint32_t* mtile, const uint16_t* list,
                                                  int from, int n, int lane, int r0, int x0, int y0, int H, int W)
 {
-    if (lane < n) {
-        const uint32_t e = list[from + lane];
-        const int rr = (int)(e >> 8), xl = (int)(e & 255u);
-        const int x = x0 + xl, y = y0 + r0 + rr;
-        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
-            const uint8_t* c = tile + (r0 + rr + 3) * FT_LW + xl + 4 * FT_X0;
-            const int p = c[0];
-            const int hi = p + 20, lo = p - 20;
-            uint32_t mb = 0, md = 0;
+    const bool act = lane < n;
+    const uint32_t e = act ? (uint32_t)list[from + lane] : 0u;
+    const int rr = (int)(e >> 8), xl = (int)(e & 255u);
+    const int x = x0 + xl, y = y0 + r0 + rr;
+    const bool ok = act && x >= 3 && x < W - 3 && y >= 3 && y < H - 3;
+    const uint8_t* c = tile + (r0 + rr + 3) * FT_LW + xl + 4 * FT_X0;
+    const uint32_t p = c[0];
+    const uint32_t hi = p + 20u;
+    const int lo = (int)p - 20;
+    unsigned long long mb[16], md[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int v = c[circ_off(k)];
-                mb |= (uint32_t)(v >= hi) << k;
-                md |= (uint32_t)(v <= lo) << k;
-            }
-            if (run12(mb) || run12(md))
-                atomicOr(&mtile[(r0 + rr) * (FT_W / 32) + (xl >> 5)], 1u << (xl & 31));
-        }
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t v = c[circ_off(k)];
+        mb[k] = __ballot(v >= hi);
+        md[k] = __ballot((int)v <= lo);
     }
+    const unsigned long long hit = (run12_lanes(mb) | run12_lanes(md)) & __ballot(ok);
+    if ((hit >> lane) & 1ull) atomicOr(&mtile[(r0 + rr) * (FT_W / 32) + (xl >> 5)], 1u << (xl & 31));
 }
 
 // Staging of one tile (aligned path): lane l reads dword l of each of this wave's LDS rows (image
@@ -359,57 +372,76 @@ __device__ __forceinline__ void fast_stage_store(const FastStage& st, uint32_t* 
     if (lane < 2 * FT_STEPS && hr < FT_LH) tile32[hr * FT_PITCH + FT_X0 + 63 + (lane & 1)] = okb ? st.vb : 0u;
 }
 
-// Staging when rows are whole aligned 16-byte groups (W % 16 == 0, 16-byte-aligned frame): one load
-// instruction moves four tile rows (lane = 16 * row + 16-byte segment), three instructions cover
-// this wave's rows (row groups w, w + 4, w + 8); the halo dwords of all 38 rows are fetched by
-// waves 2 and 3 with one instruction each.  Same clamp-then-zero rule as above.
+// Staging when rows are whole aligned 16-byte groups (W % 16 == 0, 16-byte-aligned frame).  A tile
+// row is 18 segments of 16 bytes: the 16 of the body plus one on each side, which hold the three
+// halo columns (image x = x0 - 16 + 16 * segment).  The segments of all rows are numbered row-major
+// (idx = 18 * row + segment) and thread t moves segments t, t + 256, ...; LDS rows are exactly 18
+// segments long, so segment idx lands at byte 16 * idx.  The halo columns ride in the same load
+// instructions as the body: fetching them with loads of their own (one dword per lane and row, 64
+// different cache lines per instruction) cost a third of the kernel's run time on MI355X.
+// Same clamp-then-zero rule as above.
+constexpr int FT_SEGS = FT_LH * (FT_PITCH / 4);          // 16-byte segments of a tile
+constexpr int FT_SPT = (FT_SEGS + 255) / 256;            // segments per thread
+static_assert(FT_PITCH % 4 == 0 && FT_PITCH / 4 == FT_W / 16 + 2, "a tile row is the body plus one segment per side");
 struct FastStage16 {
-    uint4 v[3];
-    uint32_t h;
+    uint4 v[FT_SPT];
 };
 
-__device__ __forceinline__ void fast_stage16_load(FastStage16& st, const uint8_t* __restrict__ img, int H,
-                                                  int W, int x0, int y0, int lane, int wave)
+// `inside` (workgroup-uniform): every segment of the tile lies inside the image, so nothing needs
+// clamping or zeroing.
+__device__ __forceinline__ bool fast_tile_inside(int H, int W, int x0, int y0)
 {
-    const int x = x0 + 16 * (lane & 15);
-    const int xc = x < W ? x : W - 16;
+    return x0 >= 16 && x0 + FT_W + 16 <= W && y0 >= 3 && y0 - 3 + FT_LH <= H;
+}
+
+__device__ __forceinline__ void fast_stage16_load(FastStage16& st, const uint8_t* __restrict__ img, int H,
+                                                  int W, int x0, int y0, bool inside)
+{
+    constexpr int SPR = FT_PITCH / 4;                        // segments per row
+    const int t = (int)threadIdx.x;
+    const int row0 = t / SPR, seg0 = t - SPR * row0;
+    if (inside) {
+        // segment t + 256 i is 256 i / SPR rows and 256 i % SPR segments further on (one wrap at most)
+        const uint32_t off0 = (uint32_t)(__mul24(y0 - 3 + row0, W) + x0 - 16 + 16 * seg0);
 #pragma unroll
-    for (int gi = 0; gi < 3; ++gi) {
-        const int y = y0 - 3 + 4 * (wave + 4 * gi) + (lane >> 4);
-        const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
-        st.v[gi] = *reinterpret_cast<const uint4*>(img + (uint32_t)(yc * W) + (uint32_t)xc);
+        for (int i = 0; i < FT_SPT; ++i) {
+            const int drow = (256 * i) / SPR, dseg = (256 * i) % SPR;
+            const bool wrap = seg0 + dseg >= SPR;
+            const uint32_t off = off0 + (uint32_t)(drow * W + 16 * dseg) + (wrap ? (uint32_t)(W - 16 * SPR) : 0u);
+            if (t + 256 * i < FT_SEGS) st.v[i] = *reinterpret_cast<const uint4*>(img + off);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < FT_SPT; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / SPR, seg = idx - SPR * row;
+            int y = y0 - 3 + row, x = x0 - 16 + 16 * seg;
+            y = y < 0 ? 0 : (y < H ? y : H - 1);
+            x = x < 0 ? 0 : (x < W ? x : W - 16);
+            if (idx < FT_SEGS) st.v[i] = *reinterpret_cast<const uint4*>(img + (uint32_t)(__mul24(y, W) + x));
+        }
     }
-    // halo: wave 2 takes tile rows 0..31, wave 3 rows 32..37 (other waves load a harmless duplicate)
-    const int hr = (wave == 3 ? 32 : 0) + (lane >> 1);
-    const int hy = y0 - 3 + hr;
-    const int hyc = hy < 0 ? 0 : (hy < H ? hy : H - 1);
-    const int hx = (lane & 1) ? x0 + 256 : x0 - 4;
-    const int hxc = hx < 0 ? 0 : (hx < W ? hx : W - 4);
-    st.h = *reinterpret_cast<const uint32_t*>(img + (uint32_t)(hyc * W) + (uint32_t)hxc);
 }
 
 __device__ __forceinline__ void fast_stage16_store(const FastStage16& st, uint32_t* tile32, int H, int W,
-                                                   int x0, int y0, int lane, int wave)
+                                                   int x0, int y0, bool inside)
 {
-    const int x = x0 + 16 * (lane & 15);
-    const bool colok = x < W;
+    constexpr int SPR = FT_PITCH / 4;
+    uint4* const lds4 = reinterpret_cast<uint4*>(tile32);
+    const int t = (int)threadIdx.x;
+    if (inside) {
 #pragma unroll
-    for (int gi = 0; gi < 3; ++gi) {
-        const int r = 4 * (wave + 4 * gi) + (lane >> 4), y = y0 - 3 + r;
-        if (r < FT_LH) {
-            const bool ok = colok && y >= 0 && y < H;
-            uint4 v = st.v[gi];
-            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(tile32 + r * FT_PITCH + FT_X0 + 4 * (lane & 15)) = v;
-        }
-    }
-    if (wave >= 2) {
-        const int hr = (wave == 3 ? 32 : 0) + (lane >> 1);
-        const int hy = y0 - 3 + hr;
-        const int hx = (lane & 1) ? x0 + 256 : x0 - 4;
-        if (hr < FT_LH && (wave == 2 || lane < 12)) {
-            const bool ok = hy >= 0 && hy < H && hx >= 0 && hx < W;
-            tile32[hr * FT_PITCH + ((lane & 1) ? FT_X0 + 64 : FT_X0 - 1)] = ok ? st.h : 0u;
+        for (int i = 0; i < FT_SPT; ++i)
+            if (t + 256 * i < FT_SEGS) lds4[t + 256 * i] = st.v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < FT_SPT; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / SPR, seg = idx - SPR * row;
+            const int y = y0 - 3 + row, x = x0 - 16 + 16 * seg;
+            uint4 v = st.v[i];
+            if (!(y >= 0 && y < H && x >= 0 && x < W)) v = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < FT_SEGS) lds4[idx] = v;
         }
     }
 }
@@ -437,42 +469,62 @@ __device__ __forceinline__ void fast_stage_bytes(uint32_t* tile32, const uint8_t
     }
 }
 
-// Phases 1, 2a, 2b for this wave's 8 rows of the staged tile.
-__device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t* mtile, uint16_t* listA,
-                                               uint16_t* listB, int lane, int wave, int x0, int y0, int H, int W)
+// Phase 1 for FT_EVAL_ROWS output rows of the staged tile, starting at tile row r0 = strip + rr0
+// (strip = first row of this wave's strip): SAD screen, one dword (4 pixels) per lane; passing dwords
+// are appended to list A as (row within the strip) << 6 | lane.
+__device__ __forceinline__ void fast_screen_rows(const uint32_t* tile32, uint16_t* listA, int& countA, int lane,
+                                                 int r0, int rr0)
 {
-    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
-    const int r0 = wave * FT_ROWS_PER_WAVE;                 // first output row of this wave (tile-local)
-    int countA = 0, countB = 0;
-
-    // ---- phase 1: SAD screen, one dword (4 pixels) per lane ----
     {
         // rw[i] = dword of tile row r0 + i at this lane's column (output row rr uses rw[rr .. rr + 6])
-        uint32_t rw[FT_ROWS_PER_WAVE + 6];
+        uint32_t rw[FT_EVAL_ROWS + 6];
 #pragma unroll
-        for (int i = 0; i < FT_ROWS_PER_WAVE + 6; ++i) rw[i] = tile32[(r0 + i) * FT_PITCH + FT_X0 + lane];
+        for (int i = 0; i < FT_EVAL_ROWS + 6; ++i) rw[i] = tile32[(r0 + i) * FT_PITCH + FT_X0 + lane];
+        // All LDS reads first, then straight-line arithmetic for the 8 rows (the lane masks stay in
+        // scalar registers), then the pushes: no LDS latency and no branch between rows.  (Reading
+        // the dwords three pixels to the right and left at their unaligned LDS addresses instead of
+        // assembling them with v_alignbyte made the kernel three times slower on MI355X.)
+        uint32_t e[FT_EVAL_ROWS], w[FT_EVAL_ROWS];
 #pragma unroll
-        for (int rr = 0; rr < FT_ROWS_PER_WAVE; ++rr) {
-            const uint32_t C = rw[rr + 3], N = rw[rr], S = rw[rr + 6];
-            const uint32_t Cp = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 - 1 + lane];
-            const uint32_t Cn = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 + 1 + lane];
-            const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3);    // pixels x+3 .. x+6
-            const uint32_t Wd = __builtin_amdgcn_alignbyte(C, Cp, 1);   // pixels x-3 .. x
-            const uint32_t sn = __builtin_amdgcn_sad_u8(N, C, 0u), ss = __builtin_amdgcn_sad_u8(S, C, 0u);
-            const uint32_t se = __builtin_amdgcn_sad_u8(E, C, 0u), sw = __builtin_amdgcn_sad_u8(Wd, C, 0u);
-            const uint32_t ns = sn < ss ? sn : ss, ew = se < sw ? se : sw;
-            const unsigned long long m = __ballot((ns > ew ? ns : ew) >= 20u);
-            list_push(listA, countA, m, lane, (uint32_t)((rr << 6) | lane));
+        for (int rr = 0; rr < FT_EVAL_ROWS; ++rr) {
+            const uint32_t cp = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 - 1 + lane];
+            const uint32_t cn = tile32[(r0 + rr + 3) * FT_PITCH + FT_X0 + 1 + lane];
+            e[rr] = __builtin_amdgcn_alignbyte(cn, rw[rr + 3], 3);    // pixels x+3 .. x+6
+            w[rr] = __builtin_amdgcn_alignbyte(rw[rr + 3], cp, 1);    // pixels x-3 .. x
         }
+        // sv[i] = SAD of tile rows r0 + i and r0 + i + 3: the north term of output row i and the
+        // south term of output row i - 3
+        uint32_t sv[FT_EVAL_ROWS + 3];
+#pragma unroll
+        for (int i = 0; i < FT_EVAL_ROWS + 3; ++i) sv[i] = __builtin_amdgcn_sad_u8(rw[i], rw[i + 3], 0u);
+        unsigned long long m[FT_EVAL_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < FT_EVAL_ROWS; ++rr) {
+            const uint32_t C = rw[rr + 3];
+            const uint32_t sn = sv[rr], ss = sv[rr + 3];
+            const uint32_t se = __builtin_amdgcn_sad_u8(e[rr], C, 0u), sw = __builtin_amdgcn_sad_u8(w[rr], C, 0u);
+            const uint32_t ns = sn < ss ? sn : ss, ew = se < sw ? se : sw;
+            m[rr] = __ballot((ns > ew ? ns : ew) >= 20u);
+        }
+#pragma unroll
+        for (int rr = 0; rr < FT_EVAL_ROWS; ++rr)
+            list_push(listA, countA, m[rr], lane, (uint32_t)(((rr0 + rr) << 6) | lane));
     }
+}
 
-    // Sparse tile (at most 16 listed dwords = 64 pixels): skip the compass screen and give every
-    // pixel of the listed dwords straight to the exact test, one batch.
-    if (countA <= 16) {
-        if (countA > 0) {
-            const int n = 4 * countA;
+// Phases 2a, 2b for the dwords on list A; r0 = first tile row of this wave's strip.
+__device__ __forceinline__ void fast_resolve(const uint32_t* tile32, uint32_t* mtile, const uint16_t* listA,
+                                             int countA, uint16_t* listB, int lane, int r0, int x0, int y0, int H, int W)
+{
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
+    int countB = 0;
+    // Few listed dwords: skip the compass screen and give every pixel of the listed dwords straight
+    // to the exact test, 16 dwords = 64 pixels per batch (a batch costs less than screening it).
+    if (countA <= FT_SPARSE) {
+        for (int d0 = 0; d0 < countA; d0 += 16) {
+            const int n = 4 * ((countA - d0) < 16 ? (countA - d0) : 16);
             if (lane < n) {
-                const uint32_t e = listA[lane >> 2];
+                const uint32_t e = listA[d0 + (lane >> 2)];
                 listB[lane] = (uint16_t)(((e >> 6) << 8) | (4 * (e & 63u) + (uint32_t)(lane & 3)));
             }
             fast_exact_batch(tile, mtile, listB, 0, n, lane, r0, x0, y0, H, W);
@@ -508,18 +560,38 @@ __device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t*
     if (countB > 0) fast_exact_batch(tile, mtile, listB, 0, countB, lane, r0, x0, y0, H, W);
 }
 
-// One workgroup per tile.  (A persistent variant that walked a strip of tiles with two LDS buffers
-// and prefetched the next tile during evaluation was measured 25-60 % SLOWER on MI355X: the extra
-// registers and LDS cut the resident workgroups per CU from 8 to 5, which cost more memory-level
-// parallelism than the prefetch bought.)
+// This wave's FT_ROWS_PER_WAVE rows of the tile, one evaluation pass after the other.
+__device__ __forceinline__ void fast_eval_tile(const uint32_t* tile32, uint32_t* mtile, uint16_t* listA,
+                                               uint16_t* listB, int lane, int wave, int x0, int y0, int H, int W)
+{
+    const int strip = wave * FT_ROWS_PER_WAVE;
+    int countA = 0;
+    for (int pass = 0; pass < FT_ROWS_PER_WAVE / FT_EVAL_ROWS; ++pass) {
+        const int rr0 = pass * FT_EVAL_ROWS;
+        if (y0 + strip + rr0 >= H) break;                     // rows below the image (wave-uniform)
+        fast_screen_rows(tile32, listA, countA, lane, strip + rr0, rr0);
+        // list A is resolved once per strip, earlier only if the next pass could overflow it
+        if (countA > FT_LIST_A - 64 * FT_EVAL_ROWS) {
+            fast_resolve(tile32, mtile, listA, countA, listB, lane, strip, x0, y0, H, W);
+            countA = 0;
+        }
+    }
+    if (countA > 0) fast_resolve(tile32, mtile, listA, countA, listB, lane, strip, x0, y0, H, W);
+}
+
+// One workgroup per tile.  The kernel is bound by vector-ALU issue, not by memory: loading and
+// staging alone run at 5.6 TB/s on MI355X (a bare read of the same tiles reaches 6.7 TB/s), and the
+// evaluation phases add their vector instructions on top.  Five workgroups are resident per CU;
+// variants that spent more LDS (longer lists, taller tiles) or more registers (a persistent
+// workgroup prefetching its next tile) lost more to the lower residency than they saved.
 __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restrict__ gray, int H,
                                                         int W, uint32_t* __restrict__ mask, int MW,
                                                         int aligned, int ntc, int ntr,
                                                         unsigned long long* __restrict__ rowcnt)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH + 4];             // 10352 B (+ the last row's right halo)
-    __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 1 KiB: the tile's corner bits
-    __shared__ uint16_t lists[4][2][FT_LIST];                     // 2 KiB per wave: lists A and B
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH];                 // 20160 B
+    __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 2 KiB: the tile's corner bits
+    __shared__ uint16_t lists[4][FT_LIST_A + FT_LIST_B];           // per wave: list A, then list B
     // 1-D grid, tile column fastest.  Neighbouring tiles read each other's edge cache lines (the
     // halo), so a tile's neighbours should run on the SAME XCD and find those lines in its L2: with
     // the plain mapping and 8 tile columns every column would be pinned to its own XCD and each tile
@@ -536,8 +608,9 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
 
     if (aligned == 16) {
         FastStage16 st;
-        fast_stage16_load(st, img, H, W, x0, y0, lane, wave);
-        fast_stage16_store(st, tile32, H, W, x0, y0, lane, wave);
+        const bool inside = fast_tile_inside(H, W, x0, y0);
+        fast_stage16_load(st, img, H, W, x0, y0, inside);
+        fast_stage16_store(st, tile32, H, W, x0, y0, inside);
     } else if (aligned == 4) {
         FastStage st;
         fast_stage_load(st, img, H, W, x0, y0, lane, wave);
@@ -545,30 +618,38 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
     } else {
         fast_stage_bytes(tile32, img, H, W, x0, y0, lane, wave);
     }
-    mtile[threadIdx.x] = 0u;
+#pragma unroll
+    for (int t = 0; t < FT_H * (FT_W / 32); t += 256) mtile[t + threadIdx.x] = 0u;
     __syncthreads();
 
-    fast_eval_tile(tile32, mtile, lists[wave][0], lists[wave][1], lane, wave, x0, y0, H, W);
+    fast_eval_tile(tile32, mtile, lists[wave], lists[wave] + FT_LIST_A, lane, wave, x0, y0, H, W);
     __syncthreads();
 
     // write the tile's mask words (FT_H rows x 8 words) and add this tile's share to the row totals:
     // (corners, corners that get a descriptor = >= 16 px from every edge, reference src/orb.cpp:156)
     // as the two halves of one 64-bit add.  rowcnt is zeroed before the launch.
-    const int row = threadIdx.x >> 3, wq = threadIdx.x & 7;
-    const int y = y0 + row, wi = (x0 >> 5) + wq;
-    uint32_t packed = 0;
-    if (y < H && wi < MW) {
-        const uint32_t m = mtile[threadIdx.x];
-        mfr[(size_t)y * MW + wi] = m;
-        const bool yv = (y - 16 >= 0) && (y + 16 < H);
-        packed = (uint32_t)__popc(m) | ((yv ? (uint32_t)__popc(m & desc_column_bits(wi, W)) : 0u) << 16);
+    const int wq = threadIdx.x & 7, wi = (x0 >> 5) + wq;
+    const uint32_t dbits = desc_column_bits(wi, W);
+    unsigned long long* const rc = rowcnt + (size_t)f * H;
+#pragma unroll
+    for (int t0 = 0; t0 < FT_H * (FT_W / 32); t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        const int y = y0 + (t >> 3);
+        int packed = 0;
+        if (y < H && wi < MW) {
+            const uint32_t m = mtile[t];
+            mfr[(uint32_t)(y * MW + wi)] = m;
+            const bool yv = (y - 16 >= 0) && (y + 16 < H);
+            packed = __popc(m) | ((yv ? __popc(m & dbits) : 0) << 16);
+        }
+        // sum over the row's 8 words = 8 consecutive lanes (at most 256 per half)
+        packed = dpp_add<0xB1, 0xf>(packed);      // quad_perm [1,0,3,2]
+        packed = dpp_add<0x4E, 0xf>(packed);      // quad_perm [2,3,0,1]
+        packed = dpp_add<0x141, 0xf>(packed);     // row_half_mirror: the other quad of the 8
+        if (wq == 0 && y < H && packed != 0)
+            atomicAdd(rc + (uint32_t)y, (unsigned long long)((uint32_t)packed & 0xFFFFu) |
+                                            ((unsigned long long)((uint32_t)packed >> 16) << 32));
     }
-    packed += __shfl_xor(packed, 1);
-    packed += __shfl_xor(packed, 2);
-    packed += __shfl_xor(packed, 4);          // sum over the row's 8 words (at most 256 per half)
-    if (wq == 0 && y < H && packed != 0u)
-        atomicAdd(rowcnt + (size_t)f * H + y,
-                  (unsigned long long)(packed & 0xFFFFu) | ((unsigned long long)(packed >> 16) << 32));
 }
 
 void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStream_t s)
@@ -742,11 +823,6 @@ __device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01)
 }
 
 // Sum over the 64 lanes with DPP adds; the total lands in lane 63 and is returned wave-uniform.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_add(int v)
-{
-    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
-}
 __device__ __forceinline__ int wave_total(int v)
 {
     v = dpp_add<0x111, 0xf>(v);   // row_shr:1
