@@ -949,11 +949,12 @@ __device__ __forceinline__ void patch_moments_bytes(const uint8_t* __restrict__ 
     t01 = wave_total(s01);
 }
 
-// Staging of one keypoint's 44-row x 12-dword window (aligned start column xa, even first row y0:
-// the 43 rows / columns a sample can reach plus alignment) into LDS rows of 64 bytes:
-// lane = 12 * rs + dw, row = rs + 5 * it.  Lanes 60..63 repeat lanes 0..3.
-constexpr int WIN_ROWS = 44, WIN_DW = 12, WIN_PITCH_DW = 16;
-constexpr int WIN_UINT4 = WIN_ROWS * WIN_PITCH_DW / 4;      // 172
+// Staging of a 45-row x 12-dword window (aligned start column xa, even first row y0: the 43 rows /
+// columns a keypoint's samples can reach, plus alignment, plus slack that lets neighbouring
+// keypoints use the same window) into LDS rows of 64 bytes: lane = 12 * rs + dw, row = rs + 5 * it.
+// Lanes 60..63 repeat lanes 0..3.
+constexpr int WIN_ROWS = 45, WIN_DW = 12, WIN_PITCH_DW = 16;
+constexpr int WIN_UINT4 = WIN_ROWS * WIN_PITCH_DW / 4;      // 180
 constexpr int ROT_UINT4 = 32;                               // 31 rotation-table entries of 16 bytes
 
 __device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int H, int W, int xa, int y0,
@@ -963,9 +964,7 @@ __device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int 
     if (xa >= 0 && xa + 4 * WIN_DW <= W && y0 >= 0 && y0 + WIN_ROWS <= H) {
         const uint32_t off = (uint32_t)(gy0 * W + gx);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) regs[it] = load_u32_at(img, off + (uint32_t)(5 * it * W));
-        // rows 40 .. 44: only rs 0 .. 3 are inside the window (the other is not written)
-        regs[8] = load_u32_at(img, rs < 4 ? off + (uint32_t)(40 * W) : off);
+        for (int it = 0; it < 9; ++it) regs[it] = load_u32_at(img, off + (uint32_t)(5 * it * W));
     } else {
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
@@ -981,8 +980,7 @@ __device__ __forceinline__ void stage_write(uint32_t* win, int dw, int rs, const
 {
     uint32_t* const p = win + rs * WIN_PITCH_DW + dw;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) p[5 * it * WIN_PITCH_DW] = regs[it];
-    if (rs < 4) p[40 * WIN_PITCH_DW] = regs[8];
+    for (int it = 0; it < 9; ++it) p[5 * it * WIN_PITCH_DW] = regs[it];
 }
 
 // 1.5 * 2^23: adding it to a float |t| < 2^22 leaves rint(t) (ties to even, the cvRound of the
@@ -990,8 +988,10 @@ __device__ __forceinline__ void stage_write(uint32_t* win, int dw, int rs, const
 constexpr float RND_MAGIC = 12582912.0f;
 constexpr uint32_t RND_MAGIC_BITS = 0x4B400000u;
 
+// At most 5 waves per SIMD: with more, the windows and patches of the resident waves no longer fit
+// the vector L1 cache and the kernel runs 10 - 15 % slower on MI355X.
 template <int KPW>
-__global__ __launch_bounds__(256) void orient_describe_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void orient_describe_kernel(
     const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
     const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
     const float* __restrict__ angle_in, float* __restrict__ kp7, float* __restrict__ angle_out,
@@ -1014,9 +1014,10 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
     // across the full width, in which consecutive keypoints are hundreds of pixels apart.  They
     // are processed in order of x instead (counting sort on 256 column buckets; the order inside a
     // bucket is whatever the atomics give and does not matter, every result goes to the keypoint's
-    // own row).  Sorted position 4 * l + w goes to lane l of wave w, so the four waves sweep the
-    // band from left to right together and successive windows overlap; that turns most of the
-    // window and patch reads into L2 hits.
+    // own row).  Wave w takes sorted positions KPW * w .. KPW * w + KPW - 1, one per lane: each wave
+    // sweeps its quarter of the band from left to right, successive windows and patches overlap (L1
+    // and L2 hits instead of HBM reads), and the corners of one cluster, which are neighbours in x,
+    // come one after the other and share one staged window.
     __shared__ int bucket_count[256];
     __shared__ int wave_sum_lds[4];
     __shared__ uint16_t order[256];
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
         __syncthreads();
         if (t < wg_n) order[bucket_count[bkt] + rank] = (uint16_t)t;
         __syncthreads();
-        const int pos = 4 * lane + wave;
+        const int pos = KPW * wave + lane;
         if (lane < KPW && pos < wg_n) kidx = order[pos];
     }
     const int nk = (int)__builtin_popcountll(__ballot(kidx >= 0));   // lanes 0 .. nk-1 hold keypoints
@@ -1148,15 +1149,23 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
             dpx2[r] = (double)(int8_t)((q >> 16) & 255u);
             dpy2[r] = (double)(int8_t)(q >> 24);
         }
+        // The window in LDS starts at column ox (a multiple of 4), row oy (even).  A keypoint whose
+        // 43 x 43 box of reachable samples lies inside the window that is already staged uses it as
+        // it is: corners come in clusters of adjacent pixels, and the wave meets them one after the
+        // other because its keypoints are consecutive in x order.
         uint32_t regs[9];
         int j = __builtin_ctzll(todo);
         todo &= todo - 1;
+        int ox, oy;
         {
             const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
-            stage_load(img, H, W, (x - 21) & ~3, (y - 21) & ~1, dw, rs, regs);
+            ox = (x - 21) & ~3;
+            oy = (y - 21) & ~1;
+            stage_load(img, H, W, ox, oy, dw, rs, regs);
         }
+        bool fresh = true;                       // regs hold a window that is not in LDS yet
         while (true) {
-            stage_write(win, dw, rs, regs);
+            if (fresh) stage_write(win, dw, rs, regs);
             const int xj = __builtin_amdgcn_readlane(p.x, j), yj = __builtin_amdgcn_readlane(p.y, j);
             const int sj = __builtin_amdgcn_readlane(slot, j);
             const double cj = __hiloint2double(__builtin_amdgcn_readlane(c_hi, j), __builtin_amdgcn_readlane(c_lo, j));
@@ -1168,12 +1177,19 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
                 reinterpret_cast<double2*>(slab[wv] + WIN_UINT4)[lane] = e;
             }
             const bool more = todo != 0ull;
-            int jn = j;
+            int jn = j, nox = ox, noy = oy;
+            fresh = false;
             if (more) {
                 jn = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int x = __builtin_amdgcn_readlane(p.x, jn), y = __builtin_amdgcn_readlane(p.y, jn);
-                stage_load(img, H, W, (x - 21) & ~3, (y - 21) & ~1, dw, rs, regs);
+                const bool covered = ox <= x - 21 && x + 21 < ox + 4 * WIN_DW && oy <= y - 21 && y + 21 < oy + WIN_ROWS;
+                if (!covered) {
+                    nox = (x - 21) & ~3;
+                    noy = (y - 21) & ~1;
+                    stage_load(img, H, W, nox, noy, dw, rs, regs);
+                    fresh = true;
+                }
             }
             unsigned long long bal[4] = {0ull, 0ull, 0ull, 0ull};
             // A non-finite angle (possible only for caller-supplied angles) makes every coordinate
@@ -1186,7 +1202,7 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
                 // in the window; the 0x4B400000 parts of row * 64 + column are a constant folded
                 // into the address.
                 float cx = (float)xj, cy = (float)yj;
-                float mx = RND_MAGIC - (float)((xj - 21) & ~3), my = RND_MAGIC - (float)((yj - 21) & ~1);
+                float mx = RND_MAGIC - (float)ox, my = RND_MAGIC - (float)oy;
                 asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my));   // vector copies: scalar operands halve the add rate
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1220,6 +1236,8 @@ __global__ __launch_bounds__(256) void orient_describe_kernel(
             }
             if (!more) break;
             j = jn;
+            ox = nox;
+            oy = noy;
         }
     } else {
         // this lane's four test pairs (one per round), as doubles
