@@ -1014,10 +1014,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     // across the full width, in which consecutive keypoints are hundreds of pixels apart.  They
     // are processed in order of x instead (counting sort on 256 column buckets; the order inside a
     // bucket is whatever the atomics give and does not matter, every result goes to the keypoint's
-    // own row).  Wave w takes sorted positions KPW * w .. KPW * w + KPW - 1, one per lane: each wave
-    // sweeps its quarter of the band from left to right, successive windows and patches overlap (L1
-    // and L2 hits instead of HBM reads), and the corners of one cluster, which are neighbours in x,
-    // come one after the other and share one staged window.
+    // own row).  The sorted sequence is dealt to the four waves in runs of 8 positions (lanes 8c ..
+    // 8c + 7 of wave w hold run 4c + w): the waves sweep the band from left to right together, so a
+    // cache line one wave fetched is an L2 hit for the other three, and the corners of one cluster,
+    // which are neighbours in x, mostly fall into one run and share one staged window.  (Runs of 64
+    // share a few more windows but triple the L2 misses; runs of 1 share none.)
     __shared__ int bucket_count[256];
     __shared__ int wave_sum_lds[4];
     __shared__ uint16_t order[256];
@@ -1044,7 +1045,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         __syncthreads();
         if (t < wg_n) order[bucket_count[bkt] + rank] = (uint16_t)t;
         __syncthreads();
-        const int pos = KPW * wave + lane;
+        constexpr int C = 8;                  // run of sorted positions per wave (KPW is a multiple)
+        const int pos = ((lane / C) * 4 + wave) * C + lane % C;
         if (lane < KPW && pos < wg_n) kidx = order[pos];
     }
     const int nk = (int)__builtin_popcountll(__ballot(kidx >= 0));   // lanes 0 .. nk-1 hold keypoints
