@@ -62,14 +62,24 @@ __device__ __forceinline__ int dpp_add(int v)
     return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// Inclusive prefix sum over the 64 lanes in seven DPP adds: three shifted copies of the input give
+// sums of 4 inside each row of 16, row_shr:4 / :8 (restricted to the lanes that have a source) finish
+// the rows, and the row totals are broadcast into the following rows.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_take(int v)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
+{
+    int s = v + dpp_take<0x111, 0xf, 0xf>(v);       // row_shr:1
+    s += dpp_take<0x112, 0xf, 0xf>(v);              // row_shr:2
+    s += dpp_take<0x113, 0xf, 0xf>(v);              // row_shr:3
+    s += dpp_take<0x114, 0xf, 0xe>(s);              // row_shr:4 into lanes 4 .. 15 of each row
+    s += dpp_take<0x118, 0xf, 0xc>(s);              // row_shr:8 into lanes 8 .. 15
+    s += dpp_take<0x142, 0xa, 0xf>(s);              // row_bcast:15 into rows 1 and 3
+    s += dpp_take<0x143, 0xc, 0xf>(s);              // row_bcast:31 into rows 2 and 3
+    return s;
 }
 
 // Bits b of mask word w whose pixel x = 32w + b satisfies x - 16 >= 0 && x + 16 < W.
@@ -727,7 +737,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
         uint32_t bits = w < MW ? mrow[w] : 0u;
         const uint32_t vb = yv ? (bits & desc_column_bits(w, W)) : 0u;
         const int c = __popc(bits), cv = __popc(vb);
-        const int ic = wave_incl_scan(c, lane), icv = wave_incl_scan(cv, lane);
+        // both counts in one scan (a row holds at most 32 * 64 corners: 16 bits each)
+        const int icc = wave_incl_scan(c | (cv << 16), lane);
+        const int ic = icc & 0xFFFF, icv = icc >> 16;
         int i = base + ic - c, iv = basev + icv - cv;
         while (bits) {
             const int b = __ffs(bits) - 1;
@@ -740,8 +752,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
             ++i;
             iv += v;
         }
-        base += __shfl(ic, 63);
-        basev += __shfl(icv, 63);
+        base += __builtin_amdgcn_readlane(ic, 63);
+        basev += __builtin_amdgcn_readlane(icv, 63);
     }
 }
 
