@@ -178,6 +178,21 @@ def test_extract_on_widths_that_exercise_every_staging_path(gctx, H, W):
     assert_extract_equal(gctx.extract_gray(img), oracle.c.extract_gray(img))
 
 
+@pytest.mark.parametrize("H,W", [(64, 512), (70, 288), (129, 528), (131, 784), (61, 1040), (200, 272), (67, 16),
+                                 (135, 560)])
+def test_extract_16_byte_aligned_sizes_around_tile_edges(gctx, H, W):
+    """W % 16 == 0 (16-byte staging, interior tiles without clamping next to border tiles with it),
+    heights around the 64-row tiles, with dense noise in one half (long candidate lists, the compass
+    screen, full exact-test batches) and structured content in the other (short lists)."""
+    rng = np.random.default_rng(H * 10007 + W)
+    img = make_test_image(H, W, 4000 + H + W)
+    img[:, : W // 2] = rng.integers(0, 256, (H, W // 2), dtype=np.uint8)
+    assert_extract_equal(gctx.extract_gray(img), oracle.c.extract_gray(img))
+    # a batch of frames through the device-resident path takes the same kernels with frames > 1
+    xy = oracle.c.detect(img[::-1].copy())
+    assert np.array_equal(gctx.detect(img[::-1].copy()), xy)
+
+
 def test_extract_fuzz_shapes_and_textures(gctx):
     """Random sizes (tiny, odd widths, widths around the tile and chunk sizes) and textures (sparse
     specks, dense noise with thousands of corners, saturated blocks): GPU == CPU restatement."""
