@@ -142,7 +142,6 @@ def main():
     alg = {
         # bytes per launch (one launch covers the rank's whole batch)
         "fast_mask": ("hbm", float(F * (H * W + H * MW8 + 8 * H))),
-        "rowcount": ("hbm", float(F * (H * MW8 + 8 * H))),
         "rowscan": ("hbm", float(F * (16 * H + 8))),
         "emit": ("hbm", float(F * H * MW8 + 8 * n.sum())),
         "orient_describe": ("hbm", float(np.minimum(H * W, 1849 * n).sum() + (8 + 4 + 28) * n.sum() + 32 * nv.sum())),
@@ -182,7 +181,7 @@ def main():
                                 "r01_pmc_traffic_1080p_1000frames.json")
     if args.preset == "1080p" and F == 1000 and os.path.exists(traffic_file):
         pmc = json.load(open(traffic_file))
-        for name, key in (("fast_mask", "fast_mask_kernel"), ("rowcount", "rowcount_kernel"),
+        for name, key in (("fast_mask", "fast_mask_kernel"),
                           ("rowscan", "rowscan_kernel"), ("emit", "emit_kernel"),
                           ("orient_describe", "orient_describe_kernel"),
                           ("knn2_expand", "expand_fp4_kernel"),
