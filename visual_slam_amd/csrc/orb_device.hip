@@ -502,19 +502,20 @@ __device__ __forceinline__ void fast_screen_rows(const uint32_t* tile32, uint16_
             e[rr] = __builtin_amdgcn_alignbyte(cn, rw[rr + 3], 3);    // pixels x+3 .. x+6
             w[rr] = __builtin_amdgcn_alignbyte(rw[rr + 3], cp, 1);    // pixels x-3 .. x
         }
-        // sv[i] = SAD of tile rows r0 + i and r0 + i + 3: the north term of output row i and the
-        // south term of output row i - 3
-        uint32_t sv[FT_EVAL_ROWS + 3];
+        // sv[i] = SAD of tile rows r0 + i and r0 + i + 3, minus 20 (the accumulator input of v_sad_u8
+        // starts at -20): the north term of output row i and the south term of output row i - 3.
+        // A term is negative iff its SAD is below 20, so "(N and S pass) or (E and W pass)" is the
+        // sign of (n | s) & (e | w) being clear: or / and issue at twice the rate of min / max.
+        int sv[FT_EVAL_ROWS + 3];
 #pragma unroll
-        for (int i = 0; i < FT_EVAL_ROWS + 3; ++i) sv[i] = __builtin_amdgcn_sad_u8(rw[i], rw[i + 3], 0u);
+        for (int i = 0; i < FT_EVAL_ROWS + 3; ++i) sv[i] = (int)__builtin_amdgcn_sad_u8(rw[i], rw[i + 3], (uint32_t)-20);
         unsigned long long m[FT_EVAL_ROWS];
 #pragma unroll
         for (int rr = 0; rr < FT_EVAL_ROWS; ++rr) {
             const uint32_t C = rw[rr + 3];
-            const uint32_t sn = sv[rr], ss = sv[rr + 3];
-            const uint32_t se = __builtin_amdgcn_sad_u8(e[rr], C, 0u), sw = __builtin_amdgcn_sad_u8(w[rr], C, 0u);
-            const uint32_t ns = sn < ss ? sn : ss, ew = se < sw ? se : sw;
-            m[rr] = __ballot((ns > ew ? ns : ew) >= 20u);
+            const int se = (int)__builtin_amdgcn_sad_u8(e[rr], C, (uint32_t)-20);
+            const int sw = (int)__builtin_amdgcn_sad_u8(w[rr], C, (uint32_t)-20);
+            m[rr] = __ballot(((sv[rr] | sv[rr + 3]) & (se | sw)) >= 0);
         }
 #pragma unroll
         for (int rr = 0; rr < FT_EVAL_ROWS; ++rr)
