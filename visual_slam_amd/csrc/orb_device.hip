@@ -1634,7 +1634,11 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     uint4 next = make_uint4(0, 0, 0, 0);
     if (tbeg < tend) next = tsrc[0];
     int run_row0 = tbeg * 32, run_tiles = 0;
-    for (int t = tbeg; t < tend; ++t) {
+    v16f pend;                                    // accumulators whose top-2 selection is still due
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pend[i] = -INFINITY;
+    // One train tile: stage it, then (waves with queries) multiply and select.  c0 = accumulator start.
+    auto step = [&](int t, const v16f& c0) {
         const int buf = (t - tbeg) & 1;
         stage[buf][threadIdx.x] = next;
         __syncthreads();
@@ -1646,30 +1650,44 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
                 const uint4 v = stage[buf][ks * 64 + lane];
                 a[ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
             }
-            auto tile = [&](const v16f& c0) {
+            // Every chain of four matrix instructions is issued together with the top-2 selection of
+            // the accumulators produced BEFORE it (the previous query tile's; for the first chain the
+            // last query tile's of the previous train tile, carried across the barrier in `pend`), so
+            // the vector instructions never wait for a matrix result and always have matrix work to
+            // overlap with.
+            v16f prev = pend;
 #pragma unroll
-                for (int u = 0; u < QT; ++u) {
-                    v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
+            for (int u = 0; u < QT; ++u) {
+                const int pu = (u + QT - 1) % QT;             // the query tile `prev` belongs to
+                v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
 #pragma unroll
-                    for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[u], m2[u], acc[i], acc[i + 1], pinf);
-                    m1[u] += 32.0f / 4096.0f;
-                    m2[u] += 32.0f / 4096.0f;
-                }
-            };
-            if ((t + 1) * 32 <= nt) {
-                tile(cin);
-            } else {                                  // last, partial tile: rows past nt never win
-                v16f c0 = cin;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
-                tile(c0);
+                for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[pu], m2[pu], prev[i], prev[i + 1], pinf);
+                m1[pu] += 32.0f / 4096.0f;
+                m2[pu] += 32.0f / 4096.0f;
+                prev = acc;
+                // schedule: one matrix instruction, then a quarter of the vector work, four times
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             }
+            pend = prev;
             ++run_tiles;
             if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
+                // end of a key run: the last query tile's accumulators are still pending
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[QT - 1], m2[QT - 1], pend[i], pend[i + 1], pinf);
+                m1[QT - 1] += 32.0f / 4096.0f;
+                m2[QT - 1] += 32.0f / 4096.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pend[i] = -INFINITY;
 #pragma unroll
                 for (int u = 0; u < QT; ++u) {
                     top2_insert(k1[u], k2[u], knn2_decode_key(m1[u], run_tiles, run_row0));
@@ -1681,6 +1699,18 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
                 run_tiles = 0;
             }
         }
+    };
+    // whole tiles first; only the very last tile of the train set can be partial
+    int tfull = nt >> 5;
+    tfull = tfull < tend ? tfull : tend;
+    int t = tbeg;
+    for (; t < tfull; ++t) step(t, cin);
+    if (t < tend) {                                   // rows past nt never win
+        v16f c0 = cin;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
+        step(t, c0);
     }
 
     if (!wave_has_queries) return;
