@@ -55,6 +55,54 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters)
     out[blockIdx.x * 256 + threadIdx.x] = m1[0] + m2[0] + m1[1] + m2[1];
 }
 
+// Software-pipelined order: every chain of four MFMAs is issued together with the selection of the
+// accumulators produced by the chain before it (one MFMA, then a quarter of the vector work, ...).
+__device__ __forceinline__ void ins2b(float& m1, float& m2, float a, float b, float pinf)
+{
+    const float s2 = __builtin_amdgcn_fmed3f(m1, a, b);
+    m1 = __builtin_fmaxf(__builtin_fmaxf(m1, a), b);
+    m2 = __builtin_amdgcn_fmed3f(s2, m2, pinf);
+}
+__global__ __launch_bounds__(256, 2) void kpipe(float* out, int iters)
+{
+    v8i a[4], b[2][4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = v8i{(int)threadIdx.x + i, 2, 3, 4, 0, 0, 0, 0};
+        b[0][i] = v8i{5, 6 + i, 7, (int)blockIdx.x, 0, 0, 0, 0};
+        b[1][i] = v8i{9, 6 + i, 1, (int)blockIdx.x, 0, 0, 0, 0};
+    }
+    v16f c0, prev;
+    for (int i = 0; i < 16; ++i) { c0[i] = -256.0f - i; prev[i] = -1e30f; }
+    float m1[2] = {-1e30f, -1e30f}, m2[2] = {-1e30f, -1e30f};
+    float pinf = __builtin_inff();
+    asm volatile("" : "+v"(pinf));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pu = u ^ 1;
+            v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, 0x7F, 0, 0x7F);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, 0x7F, 0, 0x7F);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, 0x7F, 0, 0x7F);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, 0x7F, 0, 0x7F);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) ins2b(m1[pu], m2[pu], prev[i], prev[i + 1], pinf);
+            m1[pu] += 0.0078125f;
+            m2[pu] += 0.0078125f;
+            prev = acc;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+        a[0][0] += 1;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = m1[0] + m2[0] + m1[1] + m2[1] + prev[0];
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 // Same work per unit with the 16x16x128 shape: 4 output tiles x 2 k-steps, 4 results per tile and lane.
 template <int MODE>
@@ -108,7 +156,8 @@ float run(float* d, int wgs_per_cu, int iters)
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        if (SHAPE == 32) hipLaunchKernelGGL(k<MODE>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
+        if (MODE == 4) hipLaunchKernelGGL(kpipe, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
+        else if (SHAPE == 32) hipLaunchKernelGGL(k<MODE>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
         else hipLaunchKernelGGL(k16<MODE>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, iters);
         hipEventRecord(b);
         hipEventSynchronize(b);
@@ -126,9 +175,10 @@ int main()
     for (int w = 1; w <= 4; ++w) {
         const float t1 = run<1, 32>(d, w, iters), t2 = run<2, 32>(d, w, iters), t3 = run<3, 32>(d, w, iters);
         // per SIMD and trip: w waves x 2 units x (4 MFMA = 128 cycles, 26 VALU = 104 cycles)
-        printf("%d waves/SIMD: ns per unit  mfma %.1f  valu %.1f  both %.1f   (sum %.1f)\n", w,
+        const float t4 = run<4, 32>(d, w, iters);
+        printf("%d waves/SIMD: ns per unit  mfma %.1f  valu %.1f  both %.1f   (sum %.1f)  both, software-pipelined %.1f\n", w,
                t1 * 1e6 / iters / (2 * w), t2 * 1e6 / iters / (2 * w), t3 * 1e6 / iters / (2 * w),
-               (t1 + t2) * 1e6 / iters / (2 * w));
+               (t1 + t2) * 1e6 / iters / (2 * w), t4 * 1e6 / iters / (2 * w));
         const float s1 = run<1, 16>(d, w, iters), s2 = run<2, 16>(d, w, iters), s3 = run<3, 16>(d, w, iters);
         printf("   16x16x128 shape:          mfma %.1f  valu %.1f  both %.1f\n", s1 * 1e6 / iters / (2 * w),
                s2 * 1e6 / iters / (2 * w), s3 * 1e6 / iters / (2 * w));
