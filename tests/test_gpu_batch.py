@@ -259,6 +259,41 @@ def test_long_train_set_without_train_split(eng):
         del out
 
 
+@pytest.mark.parametrize("nt", [5121, 5153, 7000, 8193, 12001, 17000])
+def test_long_train_sets_in_one_workgroup_column(eng, nt):
+    """Train sets of 160 to 530 tiles in one workgroup column (many pairs in the launch, so no
+    train-axis split), around and beyond the 8192-row key runs.  Winners in the very last rows, ties
+    between early and late rows, queries without any close row and low-entropy rows (many equal
+    distances) must all come out as the CPU restatement has them."""
+    import torch
+    from visual_slam_amd.engine import BatchFeatures
+    cap, nq, npairs = nt + 7, 96, 2100
+    rng = np.random.default_rng(nt)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t[nt // 2:: 97] = (rng.integers(0, 2, (len(t[nt // 2:: 97]), 32)) * 255).astype(np.uint8)   # low entropy
+    q[0] = t[nt - 1]                               # exact hit in the last row only
+    q[1] = t[3]; t[nt - 2] = t[3]                  # tie: first tiles and last tile
+    late = min(5200, nt - 30)
+    q[2] = t[late]; q[2, 0] ^= 1                   # near hit far into the set
+    q[3] = t[nt - 1]; q[3, 5] ^= 0x81; t[10] = q[3]; t[10, 7] ^= 0x0F   # best late, second early
+    q[4] = t[40]; t[41] = t[40]                    # both early
+    q[5:9] = (rng.integers(0, 2, (4, 32)) * 255).astype(np.uint8)
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=eng.device)
+    desc[0, :nt] = torch.from_numpy(t).to(eng.device)
+    desc[1, :nq] = torch.from_numpy(q).to(eng.device)
+    counts = torch.tensor([[nt, nt], [nq, nq]], dtype=torch.int32, device=eng.device)
+    pairs = torch.tensor([[1, 0]] * npairs, dtype=torch.int32, device=eng.device)
+    eidx, edist = oracle.c.knn2(q, t)
+    assert eidx[0, 0] == nt - 1 and eidx[1].tolist() == [3, nt - 2] and eidx[4].tolist() == [40, 41]
+    feat = BatchFeatures(kp7=None, desc=desc, valid_idx=None, counts=counts, cap=cap)
+    out = eng.match_pairs(feat, pairs)
+    eng.sync()
+    idx = out.idx[:, :nq].cpu().numpy()
+    dist = out.dist[:, :nq].cpu().numpy()
+    assert (idx == eidx[None]).all() and (dist == edist[None]).all()
+
+
 def test_matching_properties_self_match(eng):
     """Size-independent properties: a set matched against itself finds itself at distance 0 (lowest
     index among exact duplicates), dist0 <= dist1, indices in range; repeated runs are identical."""
