@@ -229,3 +229,45 @@ def test_knn2_fuzz_sizes_around_tile_edges(gctx, matcher):
         idx, dist = gctx.knn2(q, t)
         eidx, edist = oracle.c.knn2(q, t)
         assert np.array_equal(idx, eidx) and np.array_equal(dist, edist), (nq, nt)
+
+
+def test_c_abi_rejects_bad_arguments_and_stays_usable(gctx):
+    """Raw C-ABI calls with null pointers, non-positive sizes, too many train rows, a fetch with no
+    extraction behind it: an error status each (never a crash), and the context works afterwards."""
+    import ctypes
+    from visual_slam_amd import _lib
+    L = _lib.lib()
+    h = gctx._h
+    img = make_test_image(64, 80, 77)
+    p = ctypes.c_void_p(img.ctypes.data)
+    n = ctypes.c_int(0)
+    nv = ctypes.c_int(0)
+    xy = np.zeros((16, 2), np.int32)
+    pxy = ctypes.c_void_p(xy.ctypes.data)
+    assert L.orbamd_detect(None, p, 64, 80, pxy, 16, ctypes.byref(n)) == _lib.E_BADARG
+    assert L.orbamd_detect(h, None, 64, 80, pxy, 16, ctypes.byref(n)) == _lib.E_BADARG
+    assert L.orbamd_detect(h, p, 0, 80, pxy, 16, ctypes.byref(n)) == _lib.E_BADARG
+    assert L.orbamd_detect(h, p, 64, -1, pxy, 16, ctypes.byref(n)) == _lib.E_BADARG
+    assert L.orbamd_detect(h, p, 64, 80, pxy, 16, None) == _lib.E_BADARG
+    assert L.orbamd_detect(h, p, 64, 80, None, 16, ctypes.byref(n)) == _lib.E_BADARG
+    assert L.orbamd_extract_gray(h, None, 64, 80, ctypes.byref(n), ctypes.byref(nv)) == _lib.E_BADARG
+    ang = np.zeros(16, np.float32)
+    assert L.orbamd_orient(h, p, 64, 80, None, 4, ctypes.c_void_p(ang.ctypes.data)) == _lib.E_BADARG
+    assert L.orbamd_orient(h, p, 64, 80, pxy, -1, ctypes.c_void_p(ang.ctypes.data)) == _lib.E_BADARG
+    q = np.zeros((4, 32), np.uint8)
+    out = np.zeros((4, 2), np.int32)
+    pq, po = ctypes.c_void_p(q.ctypes.data), ctypes.c_void_p(out.ctypes.data)
+    assert L.orbamd_knn2(h, pq, 4, pq, 1 << 18, po, po) == _lib.E_BADARG          # train rows must be < 2^18
+    assert L.orbamd_knn2(h, pq, -1, pq, 4, po, po) == _lib.E_BADARG
+    assert L.orbamd_knn2(h, None, 4, pq, 4, po, po) == _lib.E_BADARG
+    assert L.orbamd_knn2(h, pq, 4, None, 4, po, po) == _lib.E_BADARG
+    assert L.orbamd_ctx_set_matcher(h, 99) == _lib.E_BADARG
+    fresh = _lib.Context(gctx.device)
+    try:
+        st = L.orbamd_fetch(fresh._h, pxy, pxy, pxy)
+        assert st in (_lib.E_STATE, _lib.E_BADARG)
+    finally:
+        fresh.close()
+    assert _lib.status_string(_lib.E_BADARG) and _lib.status_string(_lib.E_CAPACITY)
+    # the shared context is still fine
+    assert_extract_equal(gctx.extract_gray(img), oracle.c.extract_gray(img))
