@@ -54,9 +54,12 @@ const char* orbamd_status_string(int status);
 /* Create a context on HIP device `device` with its own non-blocking stream. */
 int orbamd_ctx_create(int device, orbamd_ctx** out);
 int orbamd_ctx_destroy(orbamd_ctx* ctx);
-/* Use a caller-owned hipStream_t (passed as void*) for all later work; NULL restores the
- * context's own stream. */
+/* Use a caller-owned hipStream_t (passed as void*) for all later work.  The handle is taken as it
+ * is: NULL means HIP's default (null) stream, the stream a host framework reports when its current
+ * stream is the default one.  Work queued before the call is waited for. */
 int orbamd_ctx_set_stream(orbamd_ctx* ctx, void* hip_stream);
+/* Go back to the context's own non-blocking stream (the state after orbamd_ctx_create). */
+int orbamd_ctx_use_own_stream(orbamd_ctx* ctx);
 /* Block until everything enqueued on the context's stream has finished. */
 int orbamd_ctx_sync(orbamd_ctx* ctx);
 /* Text of the last HIP failure seen by this context ("" if none). */

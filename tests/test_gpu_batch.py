@@ -22,6 +22,13 @@ def eng():
     return OrbEngine(0, cap=4096)
 
 
+@pytest.fixture(scope="module")
+def eng8k():
+    """Capacity for the 1080p preset (about 5k keypoints per frame)."""
+    from visual_slam_amd.engine import OrbEngine
+    return OrbEngine(0, cap=8192)
+
+
 def test_golden_fixtures(gctx):
     golden_util.check_impl_against_golden(gctx)
 
@@ -93,6 +100,51 @@ def test_pipelined_extract_and_match_equals_separate_calls(eng, frames, chunks):
                 assert torch.equal(m.idx[i - 1, :nv], ref_m.idx[i - 1, :nv])
                 assert torch.equal(m.dist[i - 1, :nv], ref_m.dist[i - 1, :nv])
                 assert torch.equal(m.good[i - 1, :nv], ref_m.good[i - 1, :nv])
+
+
+def test_pipelined_matching_waits_for_its_own_extraction(eng8k):
+    """Frames large enough that extraction takes longer than launching the matcher: the matching of a
+    frame range must be ordered behind the extraction of that range on whatever stream the engine is
+    bound to -- including the framework's default stream, whose handle is NULL."""
+    eng = eng8k
+    import torch
+    P = synth.PRESETS["1080p"]
+    frames, chunks = 20, 3
+    assert eng.stream.cuda_stream == torch.cuda.current_stream(eng.device).cuda_stream
+    for r in range(3):
+        g = eng.synth_frames(frames, P["H"], P["W"], first_frame=3000 + 20 * r, cell=P["cell"], density=P["density"])
+        ref_f = eng.extract_batch(g)
+        ref_m = eng.match_consecutive(ref_f)
+        torch.cuda.synchronize()
+        f = eng.alloc_features(frames)
+        m = eng.alloc_matches(frames - 1)
+        m.idx.fill_(-7); m.dist.fill_(-7)
+        eng.extract_and_match(g, f, m, chunks=chunks)
+        torch.cuda.synchronize()
+        assert torch.equal(f.counts, ref_f.counts)
+        for i in range(1, frames):
+            nv = int(ref_f.counts[i, 1])
+            assert torch.equal(f.desc[i, :nv], ref_f.desc[i, :nv])
+            assert torch.equal(m.idx[i - 1, :nv], ref_m.idx[i - 1, :nv]), (r, i)
+            assert torch.equal(m.dist[i - 1, :nv], ref_m.dist[i - 1, :nv]), (r, i)
+
+
+def test_engine_results_are_ordered_on_the_current_torch_stream(eng8k):
+    """No explicit synchronisation: a torch operation queued on the current stream right after the
+    engine calls must see their results (the library runs on the stream the engine was bound to)."""
+    eng = eng8k
+    import torch
+    P = synth.PRESETS["1080p"]
+    g = eng.synth_frames(12, P["H"], P["W"], first_frame=77, cell=P["cell"], density=P["density"])
+    f = eng.alloc_features(12)
+    f.counts.fill_(-1)
+    eng.extract_batch(g, out=f)
+    snap = f.counts.clone()                 # queued behind the extraction, no sync in between
+    m = eng.match_consecutive(f)
+    first = m.idx[:, :64].clone()
+    torch.cuda.synchronize()
+    assert (snap[:, 0] > 1000).all() and torch.equal(snap, f.counts)
+    assert torch.equal(first, m.idx[:, :64]) and (first[:, :, 0] >= 0).all()
 
 
 def test_batch_ratio_filter_lists_match_oracle(eng):

@@ -31,6 +31,7 @@ SIGNATURES = {
     "orbamd_ctx_create": (_int, [_int, ctypes.POINTER(_c_ctx)]),
     "orbamd_ctx_destroy": (_int, [_c_ctx]),
     "orbamd_ctx_set_stream": (_int, [_c_ctx, _vp]),
+    "orbamd_ctx_use_own_stream": (_int, [_c_ctx]),
     "orbamd_ctx_sync": (_int, [_c_ctx]),
     "orbamd_last_error": (ctypes.c_char_p, [_c_ctx]),
     "orbamd_ctx_set_matcher": (_int, [_c_ctx, _int]),
@@ -148,7 +149,11 @@ class Context:
         return st
 
     def set_stream(self, stream_ptr):
+        """Run all later work on this hipStream_t handle; 0 / None is HIP's default (null) stream."""
         self._chk(lib().orbamd_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)), "set_stream")
+
+    def use_own_stream(self):
+        self._chk(lib().orbamd_ctx_use_own_stream(self._h), "use_own_stream")
 
     def sync(self):
         self._chk(lib().orbamd_ctx_sync(self._h), "sync")

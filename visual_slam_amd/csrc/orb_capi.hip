@@ -388,7 +388,18 @@ int orbamd_ctx_set_stream(orbamd_ctx* c, void* hip_stream)
     CHK(enter(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     CHK(drain_timing(c));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    // The handle is used as given: NULL is HIP's default (null) stream, which is what a host framework
+    // whose current stream is the default one hands over.
+    c->stream = (hipStream_t)hip_stream;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_use_own_stream(orbamd_ctx* c)
+{
+    CHK(enter(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(drain_timing(c));
+    c->stream = c->own_stream;
     return ORBAMD_OK;
 }
 
