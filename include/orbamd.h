@@ -168,7 +168,10 @@ int orbamd_bgr2gray_dev(orbamd_ctx* ctx, const uint8_t* d_bgr, int frames, int H
  *   d_valid_idx int32   [frames, cap]
  *   d_counts    int32   [frames, 2] = (n, nv) -- the TRUE totals; when n > cap only the first
  *                                      cap keypoints (and their descriptors) are stored.
- * Rows past the counts are left untouched. */
+ * Rows past the counts are left untouched.  A frame with n > cap is an overflow the caller has to
+ * handle (larger cap, extract again): its stored descriptors are those of the first cap keypoints,
+ * i.e. fewer than min(nv, cap) rows, and the matching entry points, which take min(nv, cap) rows
+ * of every frame, would read rows of such a frame that were never written. */
 int orbamd_extract_batch_dev(orbamd_ctx* ctx, const uint8_t* d_gray, int frames, int H, int W,
                              int cap, float* d_kp7, uint8_t* d_desc, int32_t* d_valid_idx,
                              int32_t* d_counts);
