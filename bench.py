@@ -35,6 +35,10 @@ INT_VALU_MEASURED_MIX_TOPS = 49.2
 # Dense FP4 matrix-core peak (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4): 256 CUs x 4 SIMDs
 # x 4096 FLOP/clk x 2.4 GHz.
 MFMA_FP4_PEAK_TFLOPS = 10066.0
+# What the matcher's own inner pattern (four FP4 MFMAs + the 24-instruction top-2 selection of their 16
+# results per lane) sustains in a register-only loop at 4 waves per SIMD on MI355X: 88 ns per 32x32x256
+# unit and SIMD (visual_slam_amd/csrc/micro/mfma_top2_pattern.hip) = 1024 SIMDs x 524288 FLOP / 88 ns.
+MFMA_FP4_MEASURED_PATTERN_TFLOPS = 6100.0
 
 
 def parse_args():
@@ -167,7 +171,9 @@ def main():
             ach = work / avg_s / 1e12
             rooflines[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "avg_ms": ms / launches,
-                               "operands": "fp4 e2m1 (+-1.0, exact), f32 accumulate"}
+                               "operands": "fp4 e2m1 (+-1.0, exact), f32 accumulate",
+                               "peak_measured_pattern": MFMA_FP4_MEASURED_PATTERN_TFLOPS,
+                               "frac_of_measured_pattern": ach / MFMA_FP4_MEASURED_PATTERN_TFLOPS}
         else:
             ach = work / avg_s / 1e12
             rooflines[name] = {"bound": "int_valu", "achieved": ach, "peak": INT_VALU_PEAK_TOPS,
