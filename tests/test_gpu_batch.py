@@ -147,6 +147,42 @@ def test_engine_results_are_ordered_on_the_current_torch_stream(eng8k):
     assert torch.equal(first, m.idx[:, :64]) and (first[:, :, 0] >= 0).all()
 
 
+def test_two_frame_ranges_on_one_gpu_reproduce_the_single_batch(eng):
+    """The seam logic of the multi-GPU scheduler with device tensors (everything but the transport):
+    range B's first frame is matched against range A's last frame, which arrives as the packed
+    boundary message; all pairs together equal the matches of the undivided sequence."""
+    import torch
+    from visual_slam_amd.scheduler import pack_boundary, unpack_boundary, partition_frames, boundary_message_bytes
+    H, W, frames = 160, 224, 11
+    a = np.stack([synth.synth_frame(H, W, 300 + f, cell=12) for f in range(frames)])
+    g = torch.from_numpy(a).to(eng.device)
+    whole_f = eng.extract_batch(g)
+    whole_m = eng.match_consecutive(whole_f)
+    (a0, a1), (b0, b1) = partition_frames(frames, 2)
+    fa = eng.extract_batch(g[a0:a1])
+    ma = eng.match_consecutive(fa)
+    msg = pack_boundary(fa, fa.frames - 1, with_keypoints=True)
+    assert msg.numel() == boundary_message_bytes(fa.cap, True) and msg.is_cuda
+    wire = msg.clone()                                   # what the neighbour would receive
+    fb = eng.extract_batch(g[b0:b1])
+    mb = eng.match_consecutive(fb)
+    bnd = unpack_boundary(wire, fb.cap, True)
+    seam = eng.match_cross(fb, 0, bnd.desc, bnd.counts)
+    torch.cuda.synchronize()
+    assert bnd.counts[0].tolist() == whole_f.counts[a1 - 1].tolist()
+    n_last = int(whole_f.counts[a1 - 1, 0])
+    assert torch.equal(bnd.kp7[0, :n_last], whole_f.kp7[a1 - 1, :n_last])
+    for p in range(frames - 1):                          # pair p = frame p + 1 against frame p
+        nv = int(whole_f.counts[p + 1, 1])
+        if p + 1 < a1:
+            got = ma.idx[p, :nv], ma.dist[p, :nv]
+        elif p + 1 == b0:
+            got = seam.idx[0, :nv], seam.dist[0, :nv]
+        else:
+            got = mb.idx[p - b0, :nv], mb.dist[p - b0, :nv]
+        assert torch.equal(got[0], whole_m.idx[p, :nv]) and torch.equal(got[1], whole_m.dist[p, :nv]), p
+
+
 def test_batch_ratio_filter_lists_match_oracle(eng):
     """Device-side ratio-filter lists for consecutive pairs and for an explicit pair list."""
     import torch
