@@ -149,7 +149,6 @@ def main():
         "rowscan": ("hbm", float(F * (16 * H + 8))),
         "emit": ("hbm", float(F * H * MW8 + 8 * n.sum())),
         "orient_describe": ("hbm", float(np.minimum(H * W, 1849 * n).sum() + (8 + 4 + 28) * n.sum() + 32 * nv.sum())),
-        "knn2_expand": ("hbm", float((32 + 128) * nv.sum())),
     }
     if args.matcher == "valu":
         # integer operations per launch: 8 XOR + 8 popcount-accumulate per descriptor pair
@@ -190,7 +189,6 @@ def main():
         for name, key in (("fast_mask", "fast_mask_kernel"),
                           ("rowscan", "rowscan_kernel"), ("emit", "emit_kernel"),
                           ("orient_describe", "orient_describe_kernel"),
-                          ("knn2_expand", "expand_fp4_kernel"),
                           ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
             if name in rooflines and key in pmc:
                 rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]

@@ -87,8 +87,7 @@ int orbamd_ctx_set_matcher(orbamd_ctx* ctx, int matcher);
 #define ORBAMD_K_KNN2_MERGE 7
 #define ORBAMD_K_SYNTH      8
 #define ORBAMD_K_RATIO      9
-#define ORBAMD_K_KNN2_EXPAND 10
-#define ORBAMD_K_COUNT      11
+#define ORBAMD_K_COUNT      10
 int orbamd_ctx_timing_enable(orbamd_ctx* ctx, int on);
 int orbamd_ctx_timing_reset(orbamd_ctx* ctx);
 int orbamd_ctx_timing_read(orbamd_ctx* ctx, double ms_out[ORBAMD_K_COUNT], long launches_out[ORBAMD_K_COUNT]);

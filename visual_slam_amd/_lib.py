@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liborbamd.so")
 
 OK, E_BADARG, E_CAPACITY, E_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 MAX_TRAIN = 1 << 18
-K_COUNT = 11
+K_COUNT = 10
 MATCHER_MATRIX, MATCHER_VALU = 0, 1
 
 _c_ctx = ctypes.c_void_p

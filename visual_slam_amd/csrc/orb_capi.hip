@@ -35,7 +35,7 @@ struct orbamd_ctx {
 
     // work buffers
     DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle;
-    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount, xq, xt;
+    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
     int matcher = ORBAMD_MATCHER_MATRIX;
     int32_t* h_counts = nullptr;  // pinned, 4 ints
 
@@ -216,8 +216,6 @@ int choose_splits(int nq, int nt, int npairs, int rows_per_block, int target)
     return (int)s;
 }
 
-size_t fp4_image_bytes(int rows) { return (size_t)((rows + 31) / 32) * 4096; }
-
 int run_knn2(orbamd_ctx* c, Knn2Args& a)
 {
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
@@ -229,36 +227,6 @@ int run_knn2(orbamd_ctx* c, Knn2Args& a)
         CHK(ensure(c, c->partial, (size_t)a.npairs * a.splits * a.cap * 2 * sizeof(uint32_t)));
         a.partial = (uint32_t*)c->partial.p;
     }
-    if (matrix) {
-        a.xq_stride = fp4_image_bytes(nqmax);
-        a.xt_stride = fp4_image_bytes(ntmax);
-        const bool one_batch = !a.pairs && a.qcounts && a.qdesc == a.tdesc && a.qcounts == a.tcounts &&
-                               a.qframe0 == a.tframe0;
-        if (one_batch) {
-            CHK(ensure(c, c->xq, (size_t)(a.npairs + 1) * a.xq_stride));
-        } else {
-            CHK(ensure(c, c->xq, (size_t)a.npairs * a.xq_stride));
-            CHK(ensure(c, c->xt, (size_t)a.npairs * a.xt_stride));
-        }
-        Timed t(c, ORBAMD_K_KNN2_EXPAND);
-        if (one_batch) {
-            // consecutive pairs of one batch: every frame is expanded once and used on both sides
-            launch_expand_fp4(a.qdesc, a.qcounts, nullptr, 0, a.tframe0, a.npairs + 1, a.cap, 0,
-                              (uint8_t*)c->xq.p, a.xq_stride, c->stream);
-            a.xq = a.xt = (const uint8_t*)c->xq.p;
-            a.qslot0 = 1;
-            a.tslot0 = 0;
-        } else {
-            launch_expand_fp4(a.qdesc, a.qcounts, a.pairs, 0, a.qframe0 + 1, a.npairs, a.cap, a.nq_fixed,
-                              (uint8_t*)c->xq.p, a.xq_stride, c->stream);
-            launch_expand_fp4(a.tdesc, a.tcounts, a.pairs, 1, a.tframe0, a.npairs, a.cap, a.nt_fixed,
-                              (uint8_t*)c->xt.p, a.xt_stride, c->stream);
-            a.xq = (const uint8_t*)c->xq.p;
-            a.xt = (const uint8_t*)c->xt.p;
-            a.qslot0 = a.tslot0 = 0;
-        }
-    }
-    if (matrix) CHK(post_launch(c, "expand_fp4_kernel"));
     {
         Timed t(c, ORBAMD_K_KNN2);
         if (matrix) launch_knn2_mfma(a, c->stream);
@@ -329,8 +297,7 @@ const char* orbamd_status_string(int status)
 const char* orbamd_kernel_name(int kind)
 {
     static const char* names[ORBAMD_K_COUNT] = {"bgr2gray", "fast_mask", "rowcount", "rowscan", "emit",
-                                                "orient_describe", "knn2", "knn2_merge", "synth", "ratio_compact",
-                                                "knn2_expand"};
+                                                "orient_describe", "knn2", "knn2_merge", "synth", "ratio_compact"};
     return (kind >= 0 && kind < ORBAMD_K_COUNT) ? names[kind] : "?";
 }
 
@@ -371,7 +338,7 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
-                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->xq, &c->xt, &c->idx, &c->dist, &c->good,
+                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->idx, &c->dist, &c->good,
                       &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);

@@ -12,8 +12,8 @@
 //   orient_describe_kernel  256 keypoints per workgroup in x order, 64 per wavefront: 31x31 moments
 //                           (four keypoints per step), atan2 / cos / sin once per lane, steered
 //                           BRIEF-256 from an LDS-staged window
-//   expand_fp4_kernel       descriptor bits -> +-1 FP4 operand image for the matrix-core matcher
-//   knn2_mfma_kernel        Hamming top-2 on the matrix cores (default)
+//   knn2_mfma_kernel        Hamming top-2 on the matrix cores (default); descriptor bits become +-1 FP4
+//                           operands on the way into registers / LDS
 //   knn2_kernel             Hamming top-2 by XOR + popcount, one query per lane, train rows broadcast
 //   knn2_merge_kernel       merges train-axis partial results
 //   ratio_compact_kernel, ratio_compact_batch_kernel   ordered lists of the matches that pass the ratio test
@@ -1493,40 +1493,27 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
 // end) the keys are decoded into the integer (distance << 18) | index form and merged there.
 // Lanes l and l + 32 hold disjoint train rows of the same query and are merged at the end.
 //
-// Operand image ("FP4 image") of one descriptor set: tiles of 32 rows, 4096 bytes per tile laid
-// out as [piece 0..7][row 0..31][16 bytes]; piece p holds descriptor dword p as 32 nibbles, dword s
-// of the piece taking bits s, s + 4, ..., s + 28.  A lane's operand for k-step ks is the 16 bytes
-// at tile + ks * 1024 + lane * 16, so fragments are read with lane-linear 16-byte accesses both
-// from global memory and from LDS.  The bit-to-k assignment is the same for both operands, which
-// is all a dot product needs.
+// Operands: a tile of 32 descriptor rows is 4096 bytes of FP4 values laid out as
+// [piece 0..7][row 0..31][16 bytes]; piece p holds descriptor dword p as 32 nibbles.  A lane's
+// operand for k-step ks is the 16 bytes at ks * 1024 + lane * 16, i.e. dword 2 ks + (lane / 32) of
+// row lane % 32.  Query operands are built in registers from the descriptor dwords once per wave;
+// train tiles are fetched as plain descriptor dwords (a quarter of the bytes of an expanded image),
+// expanded by the thread that stages them and read from LDS with lane-linear 16-byte accesses.
 // ---------------------------------------------------------------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void expand_fp4_kernel(const uint8_t* __restrict__ desc,
-                                                         const int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ pairs, int side,
-                                                         int frame0, int cap, int n_fixed,
-                                                         uint8_t* __restrict__ x, size_t xstride)
+// 32 descriptor bits -> 32 FP4 (E2M1) values +-1.0 in four dwords: nibble = sign bit | 0b0010.  Dword s
+// of the result takes bits s, s + 4, ..., s + 28; both operands of a product use this assignment,
+// which is all a dot product needs.
+__device__ __forceinline__ uint4 fp4_of_bits(uint32_t w)
 {
-    const int slot = blockIdx.y, tile = blockIdx.x;
-    int f = 0, n = n_fixed;
-    if (counts) {
-        f = pairs ? pairs[2 * slot + side] : frame0 + slot;
-        n = counts[2 * f + 1];
-        n = n < cap ? n : cap;
-    }
-    if (tile * 32 >= n) return;
-    const int p = threadIdx.x >> 5, r = threadIdx.x & 31;
-    const int row = tile * 32 + r;
-    uint32_t w = 0;
-    if (row < n) w = reinterpret_cast<const uint32_t*>(desc + ((size_t)f * cap + row) * 32)[p];
     uint4 o;
-    o.x = ((w << 3) & 0x88888888u) | 0x22222222u;   // nibble = sign bit | 0b010 (magnitude 1.0)
-    o.y = ((w << 2) & 0x88888888u) | 0x22222222u;
-    o.z = ((w << 1) & 0x88888888u) | 0x22222222u;
-    o.w = (w & 0x88888888u) | 0x22222222u;
-    reinterpret_cast<uint4*>(x + (size_t)slot * xstride + (size_t)tile * 4096)[threadIdx.x] = o;
+    o.x = ((w << 3) | 0x22222222u) & 0xAAAAAAAAu;
+    o.y = ((w << 2) | 0x22222222u) & 0xAAAAAAAAu;
+    o.z = ((w << 1) | 0x22222222u) & 0xAAAAAAAAu;
+    o.w = (w | 0x22222222u) & 0xAAAAAAAAu;
+    return o;
 }
 
 // Two new keys a, b into the running pair m1 >= m2 in three instructions: with s1 >= s2 >= s3 the
@@ -1560,9 +1547,8 @@ constexpr int KNN2_RUN_TILES = 256;   // 8192 rows: the index field of a float k
 // At least two workgroups per CU (<= 256 registers per lane): with that bound the compiler keeps
 // the accumulators in ordinary VGPRs, which the top-2 instructions can read directly.
 template <int QT, bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __restrict__ xq,
-                                                        const uint8_t* __restrict__ xt, size_t xq_stride,
-                                                        size_t xt_stride, int qslot0, int tslot0,
+__global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __restrict__ qdesc,
+                                                        const uint8_t* __restrict__ tdesc,
                                                         const int32_t* __restrict__ qcounts,
                                                         const int32_t* __restrict__ tcounts,
                                                         const int32_t* __restrict__ pairs, int qframe0,
@@ -1582,9 +1568,8 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
         zsplit = (int)(rem / (uint32_t)nbp);
         qblk = (int)(rem - (uint32_t)zsplit * (uint32_t)nbp);
     }
-    int nq = nq_fixed, nt = nt_fixed;
+    int nq = nq_fixed, nt = nt_fixed, qf = 0, tf = 0;
     if (qcounts) {
-        int qf, tf;
         if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
         else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
         nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
@@ -1597,17 +1582,19 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     const int qtile0 = (qblk * 4 + wave) * QT;
     const bool wave_has_queries = qtile0 * 32 < nq;   // waves without queries only help staging
 
-    const uint8_t* xqf = xq + (size_t)(pair + qslot0) * xq_stride;
-    const uint8_t* xtf = xt + (size_t)(pair + tslot0) * xt_stride;
+    // descriptor rows of this pair, 8 dwords each (rows past the counts are never read)
+    const uint32_t* __restrict__ qrows = reinterpret_cast<const uint32_t*>(qdesc) + (size_t)qf * cap * 8;
+    const uint32_t* __restrict__ trows = reinterpret_cast<const uint32_t*>(tdesc) + (size_t)tf * cap * 8;
 
+    // query operands: lane (h, r) of k-step ks holds dword 2 ks + h of query row r as 32 FP4 values
     v8i b[QT][4];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
+        const int qrow = (qtile0 + u) * 32 + (lane & 31);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((qtile0 + u) * 32 < nq)
-                v = reinterpret_cast<const uint4*>(xqf + (size_t)(qtile0 + u) * 4096 + ks * 1024)[lane];
+            const uint32_t w = qrow < nq ? qrows[(size_t)qrow * 8 + 2 * ks + h] : 0u;
+            const uint4 v = fp4_of_bits(w);
             b[u][ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
         }
     }
@@ -1630,9 +1617,16 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     const int scale_one = 0x7F;   // E8M0 exponent 127 = 2^0
     float pinf = INFINITY;
     asm volatile("" : "+v"(pinf));   // keep +inf in a register (not a literal operand)
-    const uint4* __restrict__ tsrc = reinterpret_cast<const uint4*>(xtf) + (size_t)tbeg * 256 + threadIdx.x;
-    uint4 next = make_uint4(0, 0, 0, 0);
-    if (tbeg < tend) next = tsrc[0];
+    // staging: thread (piece = t / 32, row = t % 32) fetches dword `piece` of the tile's row `row` and
+    // writes it to LDS as 32 FP4 values, which is the 16-byte operand of lane (piece & 1, row) at
+    // k-step piece / 2
+    const int srow = threadIdx.x & 31, spiece = threadIdx.x >> 5;
+    auto fetch = [&](int t) -> uint32_t {
+        const int row = t * 32 + srow;
+        return row < nt ? trows[(size_t)row * 8 + spiece] : 0u;
+    };
+    uint32_t next = 0u;
+    if (tbeg < tend) next = fetch(tbeg);
     int run_row0 = tbeg * 32, run_tiles = 0;
     v16f pend;                                    // accumulators whose top-2 selection is still due
 #pragma unroll
@@ -1640,9 +1634,9 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     // One train tile: stage it, then (waves with queries) multiply and select.  c0 = accumulator start.
     auto step = [&](int t, const v16f& c0) {
         const int buf = (t - tbeg) & 1;
-        stage[buf][threadIdx.x] = next;
+        stage[buf][threadIdx.x] = fp4_of_bits(next);
         __syncthreads();
-        if (t + 1 < tend) next = tsrc[(size_t)(t + 1 - tbeg) * 256];
+        if (t + 1 < tend) next = fetch(t + 1);
         if (wave_has_queries) {
             v8i a[4];
 #pragma unroll
@@ -1888,16 +1882,6 @@ void launch_knn2(const Knn2Args& a, hipStream_t s)
     launch_knn2_variant<1, 4, 64>(a, s);
 }
 
-void launch_expand_fp4(const uint8_t* desc, const int32_t* counts, const int32_t* pairs, int side, int frame0,
-                       int nslots, int cap, int n_fixed, uint8_t* x, size_t xstride, hipStream_t s)
-{
-    const int nmax = counts ? cap : n_fixed;
-    if (nslots <= 0 || nmax <= 0) return;
-    dim3 grid((nmax + 31) / 32, nslots);
-    hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, s, desc, counts, pairs, side, frame0, cap, n_fixed,
-                       x, xstride);
-}
-
 void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
 {
     constexpr int QT = 2;
@@ -1905,12 +1889,12 @@ void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
     const int nbp = ((nqmax + 128 * QT - 1) / (128 * QT)) | 1;   // odd: see xcd_contiguous_item()
     dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
     if (a.splits > 1)
-        hipLaunchKernelGGL((knn2_mfma_kernel<QT, true>), grid, dim3(256), 0, s, a.xq, a.xt, a.xq_stride,
-                           a.xt_stride, a.qslot0, a.tslot0, a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+        hipLaunchKernelGGL((knn2_mfma_kernel<QT, true>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
+                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
     else
-        hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), 0, s, a.xq, a.xt, a.xq_stride,
-                           a.xt_stride, a.qslot0, a.tslot0, a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+        hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
+                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
 }
 

@@ -55,12 +55,6 @@ struct Knn2Args {
     int32_t* idx;             // [npairs][cap][2]
     int32_t* dist;            // [npairs][cap][2]
     uint8_t* good;            // [npairs][cap] or NULL
-    // Matrix-core path only: FP4 images of the two descriptor sets (launch_expand_fp4); pair p reads
-    // slot p + qslot0 of xq and slot p + tslot0 of xt.
-    const uint8_t* xq;
-    const uint8_t* xt;
-    size_t xq_stride, xt_stride;   // bytes per slot
-    int qslot0, tslot0;
 };
 // Descriptor rows (rank among keypoints >= 16 px from every edge) for a caller-supplied list;
 // counts[0] = n, counts[1] = number of descriptor rows.
@@ -77,9 +71,6 @@ void launch_ratio_compact_batch(const int32_t* idx, const uint8_t* good, const i
 void launch_knn2(const Knn2Args& a, hipStream_t s);
 // FP4 image of descriptor rows: slot s takes frame (pairs ? pairs[2 s + side] : frame0 + s) of
 // `desc` (rows per frame = cap, row counts from counts[2 f + 1]; or n_fixed rows when counts == NULL)
-// and writes ceil(rows / 32) tiles of 4096 bytes at x + s * xstride.
-void launch_expand_fp4(const uint8_t* desc, const int32_t* counts, const int32_t* pairs, int side, int frame0,
-                       int nslots, int cap, int n_fixed, uint8_t* x, size_t xstride, hipStream_t s);
 void launch_knn2_mfma(const Knn2Args& a, hipStream_t s);
 void launch_knn2_merge(const Knn2Args& a, hipStream_t s);
 
