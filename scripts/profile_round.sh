@@ -9,11 +9,13 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/write.log 2>&1
+python3 scripts/collect_traffic.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/traffic.json > $OUT/traffic.txt
+# bench.py reads the traffic figures from profiles/: use the ones just measured on this build
+cp $OUT/traffic.json $R/profiles/r01_pmc_traffic_1080p_1000frames.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 bench.py > $OUT/bench_under_rocprof.log 2>&1
 # One launch per kernel and step over the whole batch, nothing overlapped: the launches that bench.py's
 # roofline block times with HIP events (it always times them that way, whatever --chunks is).
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o serial --output-format csv -- python3 bench.py --chunks 1 > $OUT/bench_serial_under_rocprof.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $OUT -o fetch --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format csv -- python3 scripts/kbench.py --frames 1000 --reps 1 > $OUT/write.log 2>&1
-python3 scripts/collect_traffic.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/traffic.json > $OUT/traffic.txt
 cat $OUT/traffic.txt
