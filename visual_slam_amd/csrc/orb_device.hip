@@ -1508,11 +1508,13 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // which is all a dot product needs.
 __device__ __forceinline__ uint4 fp4_of_bits(uint32_t w)
 {
+    // shifts by additions (adds issue at twice the rate of shifts), then one and-or per dword
+    const uint32_t w2 = w + w, w4 = w2 + w2, w8 = w4 + w4;
     uint4 o;
-    o.x = ((w << 3) | 0x22222222u) & 0xAAAAAAAAu;
-    o.y = ((w << 2) | 0x22222222u) & 0xAAAAAAAAu;
-    o.z = ((w << 1) | 0x22222222u) & 0xAAAAAAAAu;
-    o.w = (w | 0x22222222u) & 0xAAAAAAAAu;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.x) : "v"(w8), "s"(0x88888888u), "v"(0x22222222u));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.y) : "v"(w4), "s"(0x88888888u), "v"(0x22222222u));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.z) : "v"(w2), "s"(0x88888888u), "v"(0x22222222u));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.w) : "v"(w), "s"(0x88888888u), "v"(0x22222222u));
     return o;
 }
 
@@ -1620,10 +1622,14 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     // staging: thread (piece = t / 32, row = t % 32) fetches dword `piece` of the tile's row `row` and
     // writes it to LDS as 32 FP4 values, which is the 16-byte operand of lane (piece & 1, row) at
     // k-step piece / 2
+    // (a 32-bit byte offset from the pair's first train row: scalar base + vector offset addressing)
     const int srow = threadIdx.x & 31, spiece = threadIdx.x >> 5;
+    const uint32_t soff = (uint32_t)(srow * 32 + spiece * 4);
+    const int tfull_all = nt >> 5;                // tiles below this one are whole: no row check needed
     auto fetch = [&](int t) -> uint32_t {
-        const int row = t * 32 + srow;
-        return row < nt ? trows[(size_t)row * 8 + spiece] : 0u;
+        const uint32_t off = soff + (uint32_t)t * 1024u;
+        if (t < tfull_all) return load_u32_at(reinterpret_cast<const uint8_t*>(trows), off);
+        return t * 32 + srow < nt ? load_u32_at(reinterpret_cast<const uint8_t*>(trows), off) : 0u;
     };
     uint32_t next = 0u;
     if (tbeg < tend) next = fetch(tbeg);
