@@ -15,7 +15,6 @@ python3 scripts/collect_traffic.py $OUT/fetch_counter_collection.csv $OUT/write_
 # bench.py reads the traffic figures from profiles/: use the ones just measured on this build
 cp $OUT/traffic.json $R/profiles/r01_pmc_traffic_1080p_1000frames.json
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 bench.py > $OUT/bench_under_rocprof.log 2>&1
-# One launch per kernel and step over the whole batch, nothing overlapped: the launches that bench.py's
-# roofline block times with HIP events (it always times them that way, whatever --chunks is).
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o serial --output-format csv -- python3 bench.py --chunks 1 > $OUT/bench_serial_under_rocprof.log 2>&1
+# The pipelined variant (frame ranges on two streams), for comparison.
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o pipelined --output-format csv -- python3 bench.py --chunks 4 > $OUT/bench_pipelined_under_rocprof.log 2>&1
 cat $OUT/traffic.txt
