@@ -715,16 +715,20 @@ void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_
     hipLaunchKernelGGL(rowscan_kernel, dim3(fs.frames), dim3(256), 0, s, rowcnt, fs.H, rowoff, counts);
 }
 
+constexpr int EMIT_ROWS = 4;
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                    int MW, long nrows, const int2* __restrict__ rowcnt,
                                                    const int2* __restrict__ rowoff, int cap,
                                                    int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
 {
-    const long row = (long)blockIdx.x * 4 + wave_id();
-    if (row >= nrows) return;
-    const int2 rc = rowcnt[row];
-    if (rc.x == 0) return;
+    // EMIT_ROWS consecutive rows per wave: four times fewer workgroups than one row per wave (the
+    // launch is bound by workgroup dispatch more than by its work; fetching all rows' counts and
+    // mask words ahead of the walk was slower)
+    const long row0 = ((long)blockIdx.x * 4 + wave_id()) * EMIT_ROWS;
     const int lane = lane_id();
+    for (long row = row0; row < row0 + EMIT_ROWS && row < nrows; ++row) {
+    const int2 rc = rowcnt[row];
+    if (rc.x == 0) continue;
     const long f = row / H;
     const int y = (int)(row - f * H);
     const bool yv = (y - 16 >= 0) && (y + 16 < H);
@@ -756,13 +760,14 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
         base += __builtin_amdgcn_readlane(ic, 63);
         basev += __builtin_amdgcn_readlane(icv, 63);
     }
+    }
 }
 
 void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
                  int cap, int2* kpxy, int32_t* kpslot, hipStream_t s)
 {
     long nrows = (long)fs.frames * fs.H;
-    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, mask, fs.H, fs.W,
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((nrows + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS))), dim3(256), 0, s, mask, fs.H, fs.W,
                        mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot);
 }
 
