@@ -106,7 +106,9 @@ int orbamd_detect(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
                   int32_t* out_xy, int cap, int* n_out);
 
 /* ORBDescriptor::computeOrientation (reference src/orb.cpp:110-140; include/orb.hpp:17) for n
- * caller-supplied integer keypoints; angle in degrees in [0, 360] as float. */
+ * caller-supplied integer keypoints; angle in degrees in [0, 360] as float.  Any int32 is a legal
+ * coordinate: a patch that lies outside the image has no pixels and gets angle 0, one that
+ * straddles an edge is clipped (src/orb.cpp:250). */
 int orbamd_orient(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
                   const int32_t* xy, int n, float* angle_out);
 

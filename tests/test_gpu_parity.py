@@ -84,6 +84,28 @@ def test_orient_describe_arbitrary_points(gctx):
     assert np.array_equal(gdesc, desc)
 
 
+@pytest.mark.parametrize("H,W", [(90, 112), (75, 131)])        # dword rows / byte rows
+def test_orient_describe_points_at_the_ends_of_int32(gctx, H, W):
+    """Any int32 is a legal coordinate: far-away points get angle 0 and no descriptor, points near
+    the frame get the clipped patch, and none of them may disturb the index arithmetic."""
+    img = make_test_image(H, W, 21)
+    big = 2**31 - 1
+    far = [big, big - 1, big - 15, big - 16, big - 36, big - 48, 2**30, 2**24 + 1, 70000, W + 70, W + 64,
+           W + 15, W, -big - 1, -big, -2**30, -2**24 - 1, -70000, -65, -64, -16, -15, -1, 0, 5, 40]
+    pts = [(x, y) for x in far for y in (30, -3, big, -big - 1, H + 14, H + 15)]
+    pts += [(x, y) for (y, x) in pts]
+    pts += [(40, 30), (W - 17, H - 17), (16, 16)]
+    xy = np.array(pts, dtype=np.int64).clip(-2**31, 2**31 - 1).astype(np.int32)
+    ang = oracle.c.orient(img, xy)
+    assert np.array_equal(bits(gctx.orient(img, xy)), bits(ang))
+    ang2 = np.linspace(0, 359, len(xy)).astype(np.float32)
+    desc, vidx = oracle.c.describe(img, xy, ang2)
+    gdesc, gvidx = gctx.describe(img, xy, ang2)
+    assert len(vidx) >= 3
+    assert np.array_equal(gvidx, vidx)
+    assert np.array_equal(gdesc, desc)
+
+
 def test_bgr2gray_and_extract_bgr(gctx):
     rng = np.random.default_rng(14)
     gray = make_test_image(96, 130, 15)

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(1024) void slots_kernel(const int2* __restrict__ kp
         int v = 0;
         if (i < n) {
             const int2 p = kpxy[i];
-            v = (p.y - 16 >= 0) && (p.y + 16 < H) && (p.x - 16 >= 0) && (p.x + 16 < W);
+            v = p.y >= 16 && p.y < H - 16 && p.x >= 16 && p.x < W - 16;     // (no sums: any int32 is a legal input)
         }
         const int iv = wave_incl_scan(v, lane);
         if (lane == 63) wsum[wave] = iv;
@@ -900,7 +900,7 @@ __device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ i
 
     const int gx = xa + 12 * ch, gy0 = y - 15 + rs;
     Tri32 pix[7];
-    const bool interior = xa >= 0 && xa + 36 <= W && y >= 15 && y + 15 < H;
+    const bool interior = xa >= 0 && xa <= W - 36 && y >= 15 && y < H - 15;
     if (__all(interior || !group_valid)) {
         // Lanes without work read the frame's first bytes; their masks are zero.
         const uint32_t off = lane_on ? (uint32_t)(gy0 * W + gx) : 0u;
@@ -981,7 +981,7 @@ __device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int 
                                            int dw, int rs, uint32_t (&regs)[9])
 {
     const int gx = xa + 4 * dw, gy0 = y0 + rs;
-    if (xa >= 0 && xa + 4 * WIN_DW <= W && y0 >= 0 && y0 + WIN_ROWS <= H) {
+    if (xa >= 0 && xa <= W - 4 * WIN_DW && y0 >= 0 && y0 <= H - WIN_ROWS) {
         const uint32_t off = (uint32_t)(gy0 * W + gx);
 #pragma unroll
         for (int it = 0; it < 9; ++it) regs[it] = load_u32_at(img, off + (uint32_t)(5 * it * W));
@@ -1078,6 +1078,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const int slot = (mine && desc) ? kpslot[k0 + kidx] : -1;
 
     // ---- phase A: moments, one keypoint at a time ----
+    // Caller-supplied points may be any int32.  A patch further than 15 pixels outside the image is
+    // empty wherever it is, so the moment phase works on clamped coordinates and its index
+    // arithmetic cannot overflow.
+    const int mxc = p.x < -64 ? -64 : (p.x > W + 64 ? W + 64 : p.x);
+    const int myc = p.y < -64 ? -64 : (p.y > H + 64 ? H + 64 : p.y);
     float angle = 0.0f;
     if (angle_in) {
         if (mine) angle = angle_in[k0 + kidx];
@@ -1090,7 +1095,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const int total_lane = 16 * (lane & 3) + 15;
             for (int step = 0; 4 * step < nk; ++step) {
                 const int src = 4 * step + g;
-                const int x = __shfl(p.x, src), y = __shfl(p.y, src);
+                const int x = __shfl(mxc, src), y = __shfl(myc, src);
                 int s00, s10, s01;
                 patch_moments_quad(img, H, W, x, y, src < nk, q, s00, s10, s01);
                 const int t00 = __shfl(s00, total_lane), t10 = __shfl(s10, total_lane), t01 = __shfl(s01, total_lane);
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
         } else {
             for (int j = 0; j < nk; ++j) {
-                const int x = __builtin_amdgcn_readlane(p.x, j), y = __builtin_amdgcn_readlane(p.y, j);
+                const int x = __builtin_amdgcn_readlane(mxc, j), y = __builtin_amdgcn_readlane(myc, j);
                 int t00, t10, t01;
                 patch_moments_bytes(img, H, W, x, y, lane, t00, t10, t01);
                 if (lane == j) { m00 = t00; m10 = t10; m01 = t01; }
