@@ -181,7 +181,9 @@ int orbamd_extract_batch_dev(orbamd_ctx* ctx, const uint8_t* d_gray, int frames,
  * d_pairs is int32 [npairs, 2] = (query frame, train frame); NULL means the consecutive pairs
  * (p + 1, p) for p in [0, npairs) -- current frame as query, previous as train
  * (reference views.py:88-90).  Descriptor counts are read from d_counts on the device (clamped
- * to cap), so no host round trip separates extraction from matching.
+ * to cap), so no host round trip separates extraction from matching.  A d_pairs entry that names
+ * a frame outside [0, frames) is skipped: its output rows stay untouched (and the ratio filter
+ * reports -1 kept for it).
  *   d_idx  int32 [npairs, cap, 2], d_dist int32 [npairs, cap, 2]  as orbamd_knn2
  *   d_good uint8 [npairs, cap]  1 iff both neighbours exist and dist0 < 0.75 * dist1
  *                               (reference views.py:168); may be NULL. */

@@ -73,6 +73,28 @@ def test_extract_batch_and_consecutive_matches(eng):
         eidx, edist = oracle.c.knn2(ex[qf][1], ex[tf][1])
         idx, dist, _ = mp.pair(p, len(ex[qf][1]))
         assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    # pairs that name frames outside the batch are skipped, by both matcher families and by the ratio
+    # filter; the pairs around them are computed as usual
+    pairs = torch.tensor([[1, 0], [F, 0], [2, -1], [2**31 - 1, 1], [3, 2], [0, -2**31]], dtype=torch.int32,
+                         device=eng.device)
+    from visual_slam_amd import _lib
+    for matcher in (_lib.MATCHER_MATRIX, _lib.MATCHER_VALU):
+        eng.set_matcher(matcher)
+        out = eng.alloc_matches(len(pairs), feat.cap)
+        out.idx.fill_(-77); out.dist.fill_(-77); out.good.fill_(77)
+        eng.match_pairs(feat, pairs, out=out)
+        _, _, _, kept = eng.good_matches(feat, out, pairs)
+        eng.sync()
+        for p, (qf, tf) in enumerate(pairs.cpu().tolist()):
+            if 0 <= qf < F and 0 <= tf < F:
+                eidx, edist = oracle.c.knn2(ex[qf][1], ex[tf][1])
+                idx, dist, _ = out.pair(p, len(ex[qf][1]))
+                assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+                assert int(kept[p]) == len(oracle.c.ratio_filter(eidx, edist)[0])
+            else:
+                assert bool((out.idx[p] == -77).all()) and bool((out.dist[p] == -77).all())
+                assert bool((out.good[p] == 77).all()) and int(kept[p]) == -1
+    eng.set_matcher(_lib.MATCHER_MATRIX)
 
 
 @pytest.mark.parametrize("frames,chunks", [(7, 3), (5, 5), (2, 4), (1, 4), (9, 2)])

@@ -695,6 +695,7 @@ int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d
     a.tcounts = d_counts;
     a.pairs = d_pairs;
     a.npairs = npairs;
+    a.nframes = frames;
     a.cap = cap;
     a.idx = d_idx;
     a.dist = d_dist;
@@ -715,8 +716,8 @@ int orbamd_ratio_filter_batch_dev(orbamd_ctx* c, const int32_t* d_idx, const uin
     if (npairs == 0) return ORBAMD_OK;
     {
         Timed t(c, ORBAMD_K_RATIO);
-        launch_ratio_compact_batch(d_idx, d_good, d_counts, d_pairs, npairs, cap, d_good_q, d_good_t2, d_good_t1,
-                                   d_kept, c->stream);
+        launch_ratio_compact_batch(d_idx, d_good, d_counts, d_pairs, npairs, frames, cap, d_good_q, d_good_t2,
+                                   d_good_t1, d_kept, c->stream);
     }
     return post_launch(c, "ratio_compact_batch_kernel");
 }

@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
                                                   const int32_t* __restrict__ qcounts,
                                                   const int32_t* __restrict__ tcounts,
                                                   const int32_t* __restrict__ pairs, int qframe0,
-                                                  int tframe0, int cap, int nq_fixed, int nt_fixed,
+                                                  int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
                                                   int splits, int nbp, uint32_t* __restrict__ partial,
                                                   int32_t* __restrict__ idx, int32_t* __restrict__ dist,
                                                   uint8_t* __restrict__ good)
@@ -1409,8 +1409,11 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
     }
     int qf = 0, tf = 0, nq = nq_fixed, nt = nt_fixed;
     if (qcounts) {
-        if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
-        else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
+        if (pairs) {
+            qf = pairs[2 * pair]; tf = pairs[2 * pair + 1];
+            // a pair that names a frame outside the batch is skipped (uniform over the workgroup)
+            if ((unsigned)qf >= (unsigned)nframes || (unsigned)tf >= (unsigned)nframes) return;
+        } else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
         nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
         nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
     }
@@ -1570,7 +1573,7 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
                                                         const int32_t* __restrict__ qcounts,
                                                         const int32_t* __restrict__ tcounts,
                                                         const int32_t* __restrict__ pairs, int qframe0,
-                                                        int tframe0, int cap, int nq_fixed, int nt_fixed,
+                                                        int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
                                                         int splits, int nbp, uint32_t* __restrict__ partial,
                                                         int32_t* __restrict__ idx, int32_t* __restrict__ dist,
                                                         uint8_t* __restrict__ good)
@@ -1588,8 +1591,11 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
     }
     int nq = nq_fixed, nt = nt_fixed, qf = 0, tf = 0;
     if (qcounts) {
-        if (pairs) { qf = pairs[2 * pair]; tf = pairs[2 * pair + 1]; }
-        else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
+        if (pairs) {
+            qf = pairs[2 * pair]; tf = pairs[2 * pair + 1];
+            // a pair that names a frame outside the batch is skipped (uniform over the workgroup)
+            if ((unsigned)qf >= (unsigned)nframes || (unsigned)tf >= (unsigned)nframes) return;
+        } else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
         nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
         nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
     }
@@ -1750,7 +1756,7 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
 
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ qcounts,
                                                          const int32_t* __restrict__ pairs, int qframe0,
-                                                         int cap, int nq_fixed, int splits,
+                                                         int nframes, int cap, int nq_fixed, int splits,
                                                          const uint32_t* __restrict__ partial,
                                                          int32_t* __restrict__ idx,
                                                          int32_t* __restrict__ dist,
@@ -1760,6 +1766,7 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restri
     int nq = nq_fixed;
     if (qcounts) {
         const int qf = pairs ? pairs[2 * pair] : pair + 1 + qframe0;
+        if (pairs && ((unsigned)qf >= (unsigned)nframes || (unsigned)pairs[2 * pair + 1] >= (unsigned)nframes)) return;
         nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
     }
     const int qi = blockIdx.x * 256 + threadIdx.x;
@@ -1821,8 +1828,8 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int32_t* __re
 __global__ __launch_bounds__(1024) void ratio_compact_batch_kernel(const int32_t* __restrict__ idx,
                                                                    const uint8_t* __restrict__ good,
                                                                    const int32_t* __restrict__ qcounts,
-                                                                   const int32_t* __restrict__ pairs, int cap,
-                                                                   int32_t* __restrict__ good_q,
+                                                                   const int32_t* __restrict__ pairs, int nframes,
+                                                                   int cap, int32_t* __restrict__ good_q,
                                                                    int32_t* __restrict__ good_t2,
                                                                    int32_t* __restrict__ good_t1,
                                                                    int32_t* __restrict__ kept)
@@ -1832,6 +1839,10 @@ __global__ __launch_bounds__(1024) void ratio_compact_batch_kernel(const int32_t
     __shared__ int bad;
     const int pair = blockIdx.x;
     const int qf = pairs ? pairs[2 * pair] : pair + 1;
+    if (pairs && ((unsigned)qf >= (unsigned)nframes || (unsigned)pairs[2 * pair + 1] >= (unsigned)nframes)) {
+        if (threadIdx.x == 0) kept[pair] = -1;     // a pair that names a frame outside the batch
+        return;
+    }
     int nq = qcounts[2 * qf + 1];
     nq = nq < cap ? nq : cap;
     if (threadIdx.x == 0) { carry = 0; bad = 0; }
@@ -1866,10 +1877,10 @@ __global__ __launch_bounds__(1024) void ratio_compact_batch_kernel(const int32_t
 }
 
 void launch_ratio_compact_batch(const int32_t* idx, const uint8_t* good, const int32_t* qcounts,
-                                const int32_t* pairs, int npairs, int cap, int32_t* good_q, int32_t* good_t2,
-                                int32_t* good_t1, int32_t* kept, hipStream_t s)
+                                const int32_t* pairs, int npairs, int nframes, int cap, int32_t* good_q,
+                                int32_t* good_t2, int32_t* good_t1, int32_t* kept, hipStream_t s)
 {
-    hipLaunchKernelGGL(ratio_compact_batch_kernel, dim3(npairs), dim3(1024), 0, s, idx, good, qcounts, pairs, cap,
+    hipLaunchKernelGGL(ratio_compact_batch_kernel, dim3(npairs), dim3(1024), 0, s, idx, good, qcounts, pairs, nframes, cap,
                        good_q, good_t2, good_t1, kept);
 }
 
@@ -1888,11 +1899,11 @@ static void launch_knn2_variant(const Knn2Args& a, hipStream_t s)
     dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
     if (a.splits > 1)
         hipLaunchKernelGGL((knn2_kernel<QPL, RPT, BS, true>), grid, dim3(BS), 0, s, a.qdesc, a.tdesc, a.qcounts,
-                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
+                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
                            a.partial, a.idx, a.dist, a.good);
     else
         hipLaunchKernelGGL((knn2_kernel<QPL, RPT, BS, false>), grid, dim3(BS), 0, s, a.qdesc, a.tdesc, a.qcounts,
-                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
+                           a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes, a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp,
                            a.partial, a.idx, a.dist, a.good);
 }
 
@@ -1912,11 +1923,11 @@ void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
     dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
     if (a.splits > 1)
         hipLaunchKernelGGL((knn2_mfma_kernel<QT, true>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
-                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
     else
         hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
-                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0,
+                           a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
 }
 
@@ -1924,7 +1935,7 @@ void launch_knn2_merge(const Knn2Args& a, hipStream_t s)
 {
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     dim3 grid((nqmax + 255) / 256, a.npairs);
-    hipLaunchKernelGGL(knn2_merge_kernel, grid, dim3(256), 0, s, a.qcounts, a.pairs, a.qframe0, a.cap,
+    hipLaunchKernelGGL(knn2_merge_kernel, grid, dim3(256), 0, s, a.qcounts, a.pairs, a.qframe0, a.nframes, a.cap,
                        a.nq_fixed, a.splits, a.partial, a.idx, a.dist, a.good);
 }
 

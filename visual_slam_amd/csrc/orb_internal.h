@@ -48,6 +48,7 @@ struct Knn2Args {
     const int32_t* pairs;     // [npairs][2] (query frame, train frame) or NULL = consecutive (p+1, p)
     int qframe0, tframe0;     // added to the pair's frame numbers (single cross pair: pairs == NULL, npairs == 1)
     int npairs;
+    int nframes;              // frames in the buffers: pairs[] entries outside [0, nframes) are skipped
     int cap;                  // rows per frame in qdesc/tdesc and per pair in the outputs
     int nq_fixed, nt_fixed;   // used when qcounts == NULL
     int splits;               // train-axis splits (>= 1)
@@ -66,8 +67,8 @@ void launch_ratio_compact(const int32_t* idx, const int32_t* dist, int nq, int32
 // Per pair of a batch: ordered lists of the queries whose flag in good[pair][*] is set; kept[pair] =
 // their number, or -1 when a query of the pair has fewer than two neighbours.
 void launch_ratio_compact_batch(const int32_t* idx, const uint8_t* good, const int32_t* qcounts,
-                                const int32_t* pairs, int npairs, int cap, int32_t* good_q, int32_t* good_t2,
-                                int32_t* good_t1, int32_t* kept, hipStream_t s);
+                                const int32_t* pairs, int npairs, int nframes, int cap, int32_t* good_q,
+                                int32_t* good_t2, int32_t* good_t1, int32_t* kept, hipStream_t s);
 void launch_knn2(const Knn2Args& a, hipStream_t s);
 // FP4 image of descriptor rows: slot s takes frame (pairs ? pairs[2 s + side] : frame0 + s) of
 // `desc` (rows per frame = cap, row counts from counts[2 f + 1]; or n_fixed rows when counts == NULL)
