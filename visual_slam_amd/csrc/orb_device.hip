@@ -1527,8 +1527,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // which is all a dot product needs.
 __device__ __forceinline__ uint4 fp4_of_bits(uint32_t w)
 {
-    // shifts by additions (adds issue at twice the rate of shifts), then one and-or per dword
-    const uint32_t w2 = w + w, w4 = w2 + w2, w8 = w4 + w4;
+    // three independent shifts, then one and-or per dword.  (A chain of three additions, which issue
+    // faster than shifts, measured 1 % slower: it sits on the path to the tile's barrier.)
+    const uint32_t w2 = w << 1, w4 = w << 2, w8 = w << 3;
     uint4 o;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.x) : "v"(w8), "s"(0x88888888u), "v"(0x22222222u));
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(o.y) : "v"(w4), "s"(0x88888888u), "v"(0x22222222u));
