@@ -35,6 +35,6 @@ build/%: $(CSRC)/micro/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -Wno-unused-result -o $@ $<
 
 clean:
-	rm -f $(LIB) $(MODULE) oracle/liborb_oracle.so
+	rm -f $(LIB) $(MODULE) oracle/liborb_oracle.so oracle/liborb_oracle_O0.so
 
 .PHONY: all oracle micro clean

@@ -15,7 +15,9 @@ Rank 0 prints ONE JSON line.  Besides the throughput it carries
                 on the launch stream in extra, untimed-for-`value` steps),
   rooflines     the same for every kernel of the path,
   cpu_baseline  the CPU restatement (oracle/) timed on a bounded sample of the same frames, rank 0,
-                N = 1 only; the same sample is also used to check the GPU results bit for bit.
+                N = 1 only (single thread at -O2 = `value`; beside it all host cores, and the extraction
+                built -O0 like the reference's own C++); the same sample is also used to check the GPU
+                results bit for bit.
 """
 import argparse
 import json
@@ -247,6 +249,16 @@ def main():
             ex_mt = list(pool.map(lambda i: oracle.c.extract_gray(frames_host[i]), range(S)))
             list(pool.map(lambda i: oracle.c.knn2(ex_mt[i][1], ex_mt[i - 1][1]), range(1, S)))
         cpu["all_cores"] = {"value": S / (time.perf_counter() - t0), "unit": "frames/s", "cores": ncores}
+        # Extraction compiled without optimisation, as the reference builds its own C++ (its matcher is
+        # OpenCV's optimised library, so the matching time of the -O2 run above is kept as it is).
+        S0 = min(24, S)
+        ext_O0 = oracle.c.extract_gray_unoptimised_seconds(frames_host[:S0]) / S0
+        t0 = time.perf_counter()
+        for i in range(1, min(S, 9)):
+            oracle.c.knn2(ex[i][1], ex[i - 1][1])
+        match_s = (time.perf_counter() - t0) / max(1, min(S, 9) - 1)
+        cpu["reference_build_flags"] = {"value": 1.0 / (ext_O0 + match_s), "unit": "frames/s", "cores": 1,
+                                        "sample": "%d extractions at -O0 + matching at -O2" % S0}
         ok = True
         for i in range(S):
             kp, desc, vidx = feat.frame(i)

@@ -136,6 +136,31 @@ def extract_gray(gray):
         cap = int(n)
 
 
+def extract_gray_unoptimised_seconds(frames):
+    """Wall time of the gray-frame part of extract() over `frames` with the -O0 build of the same
+    C file (the reference compiles its src/orb.cpp without optimisation, CMakeLists.txt:13).  For
+    the CPU baseline only; the results are not returned."""
+    import time
+    so = os.path.join(_HERE, "liborb_oracle_O0.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liborb_oracle_O0.so"])
+    L = ctypes.CDLL(so)
+    L.orc_extract.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_long, _u8p, _i32p,
+                              ctypes.POINTER(ctypes.c_long)]
+    L.orc_extract.restype = ctypes.c_long
+    cap = 65536
+    kp = np.empty((cap, 7), np.float32)
+    desc = np.empty((cap, 32), np.uint8)
+    vidx = np.empty(cap, np.int32)
+    nv = ctypes.c_long(0)
+    t0 = time.perf_counter()
+    for g in frames:
+        g = _gray(g)
+        L.orc_extract(_p(g, _u8p), g.shape[0], g.shape[1], _p(kp, _f32p), cap, _p(desc, _u8p), _p(vidx, _i32p),
+                      ctypes.byref(nv))
+    return time.perf_counter() - t0
+
+
 def extract(image_bgr):
     """The reference's extract(image) for [H,W,3] uint8 input (src/main_interface.cpp:80-101)."""
     kp, desc, _ = extract_gray(bgr2gray(image_bgr))
