@@ -46,12 +46,12 @@ MFMA_FP4_MEASURED_PATTERN_TFLOPS = 6100.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
     ap.add_argument("--preset", default="1080p", choices=["480p", "1080p", "4k"])
     ap.add_argument("--cap", type=int, default=0, help="keypoint capacity per frame (0 = by preset)")
-    ap.add_argument("--profile-steps", type=int, default=2, help="extra steps with per-kernel HIP events")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel HIP events")
     ap.add_argument("--cpu-sample", type=int, default=96, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="frame ranges per step whose extraction / matching are pipelined on two streams "
