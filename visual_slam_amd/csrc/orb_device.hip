@@ -715,15 +715,16 @@ void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_
     hipLaunchKernelGGL(rowscan_kernel, dim3(fs.frames), dim3(256), 0, s, rowcnt, fs.H, rowoff, counts);
 }
 
-constexpr int EMIT_ROWS = 4;
+constexpr int EMIT_ROWS = 16;
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                    int MW, long nrows, const int2* __restrict__ rowcnt,
                                                    const int2* __restrict__ rowoff, int cap,
                                                    int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
 {
-    // EMIT_ROWS consecutive rows per wave: four times fewer workgroups than one row per wave (the
-    // launch is bound by workgroup dispatch more than by its work; fetching all rows' counts and
-    // mask words ahead of the walk was slower)
+    // EMIT_ROWS consecutive rows per wave: with one row per wave the launch is bound by workgroup
+    // dispatch more than by its work (16 measured best of 1, 4, 8, 16, 32).  Fetching the next row's
+    // count, offset and mask words ahead of the walk was slower each time it was tried: many rows
+    // hold no corner, and skipping their mask words is worth more than the overlap.
     const long row0 = ((long)blockIdx.x * 4 + wave_id()) * EMIT_ROWS;
     const int lane = lane_id();
     for (long row = row0; row < row0 + EMIT_ROWS && row < nrows; ++row) {
