@@ -41,6 +41,10 @@ extern "C" {
 /* Largest train set a matcher call accepts (train indices are packed into 18 bits; OpenCV's
  * BFMatcher has the same limit). */
 #define ORBAMD_MAX_TRAIN    (1 << 18)
+/* Largest per-frame keypoint capacity (keypoint rows are addressed by 32-bit byte offsets inside
+ * a frame's arrays).  A single frame with more corners than this makes the single-frame entry
+ * points return ORBAMD_E_CAPACITY. */
+#define ORBAMD_MAX_CAP      (1 << 26)
 
 typedef struct orbamd_ctx orbamd_ctx;
 

@@ -252,6 +252,7 @@ int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
     CHK(run_detect_counts(c, d_gray, 1, H, W, (int32_t*)c->counts.p));
     CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
     const int n = c->h_counts[0], nv = c->h_counts[1];
+    if (n > ORBAMD_MAX_CAP) return ORBAMD_E_CAPACITY;
     if (n > 0) {
         CHK(run_emit(c, d_gray, 1, H, W, n));
         CHK(ensure(c, c->kp7, (size_t)n * 7 * sizeof(float)));
@@ -441,7 +442,8 @@ int orbamd_detect(orbamd_ctx* c, const uint8_t* gray, int H, int W, int32_t* out
     CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
     const int n = c->h_counts[0];
     *n_out = n;
-    const int m = n < cap ? n : cap;
+    int m = n < cap ? n : cap;
+    m = m < ORBAMD_MAX_CAP ? m : ORBAMD_MAX_CAP;
     if (m > 0) {
         CHK(run_emit(c, (const uint8_t*)c->gray.p, 1, H, W, m));
         HIPCHK(c, hipMemcpyAsync(out_xy, c->kpxy.p, (size_t)m * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
@@ -664,7 +666,9 @@ int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, i
                              float* d_kp7, uint8_t* d_desc, int32_t* d_valid_idx, int32_t* d_counts)
 {
     CHK(enter(c));
-    if (!d_gray || !d_kp7 || !d_desc || !d_counts || frames <= 0 || frames > 65535 || cap <= 0)
+    // (cap: keypoint indices are turned into 32-bit byte offsets inside a frame's arrays)
+    if (!d_gray || !d_kp7 || !d_desc || !d_counts || frames <= 0 || frames > 65535 || cap <= 0 ||
+        cap > ORBAMD_MAX_CAP)
         return ORBAMD_E_BADARG;
     CHK(check_image(H, W));
     c->have_extract = false;

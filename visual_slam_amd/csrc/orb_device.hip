@@ -715,52 +715,78 @@ void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_
     hipLaunchKernelGGL(rowscan_kernel, dim3(fs.frames), dim3(256), 0, s, rowcnt, fs.H, rowoff, counts);
 }
 
-constexpr int EMIT_ROWS = 16;
+constexpr int EMIT_ROWS = 64;       // rows per wave: one row's count and offset per lane
+constexpr int EMIT_AHEAD = 4;       // rows whose mask words are fetched together
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                    int MW, long nrows, const int2* __restrict__ rowcnt,
                                                    const int2* __restrict__ rowoff, int cap,
                                                    int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
 {
-    // EMIT_ROWS consecutive rows per wave: with one row per wave the launch is bound by workgroup
-    // dispatch more than by its work (16 measured best of 1, 4, 8, 16, 32).  Fetching the next row's
-    // count, offset and mask words ahead of the walk was slower each time it was tried: many rows
-    // hold no corner, and skipping their mask words is worth more than the overlap.
-    const long row0 = ((long)blockIdx.x * 4 + wave_id()) * EMIT_ROWS;
+    // A wave owns 64 consecutive rows (of the whole batch: a band may straddle two frames).  Lane l
+    // fetches the count and the offset of row l in one coalesced load each; only rows that hold a
+    // corner are walked (many hold none), and the mask words of the next four such rows are fetched
+    // together, so that four rows' load latencies overlap instead of adding up.
+    const long r0 = ((long)blockIdx.x * 4 + wave_id()) * EMIT_ROWS;
+    if (r0 >= nrows) return;
     const int lane = lane_id();
-    for (long row = row0; row < row0 + EMIT_ROWS && row < nrows; ++row) {
-    const int2 rc = rowcnt[row];
-    if (rc.x == 0) continue;
-    const long f = row / H;
-    const int y = (int)(row - f * H);
-    const bool yv = (y - 16 >= 0) && (y + 16 < H);
-    const uint32_t* mrow = mask + (size_t)row * MW;
-    int2* xy = kpxy + (size_t)f * cap;
-    int32_t* slot = kpslot + (size_t)f * cap;
-    const int2 off = rowoff[row];
-    int base = off.x, basev = off.y;
-    for (int w0 = 0; w0 < MW; w0 += 64) {
-        const int w = w0 + lane;
-        uint32_t bits = w < MW ? mrow[w] : 0u;
-        const uint32_t vb = yv ? (bits & desc_column_bits(w, W)) : 0u;
-        const int c = __popc(bits), cv = __popc(vb);
-        // both counts in one scan (a row holds at most 32 * 64 corners: 16 bits each)
-        const int icc = wave_incl_scan(c | (cv << 16), lane);
-        const int ic = icc & 0xFFFF, icv = icc >> 16;
-        int i = base + ic - c, iv = basev + icv - cv;
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1u;
-            const bool v = (vb >> b) & 1u;
-            if (i < cap) {
-                xy[i] = make_int2(32 * w + b, y);
-                slot[i] = v ? iv : -1;
+    const bool have = r0 + lane < nrows;
+    const int2 rc_l = have ? rowcnt[r0 + lane] : make_int2(0, 0);
+    const int2 off_l = have ? rowoff[r0 + lane] : make_int2(0, 0);
+    // frame and image row of every lane's row: one division for the 64 rows (nrows < 2^31)
+    const uint32_t f_l = (uint32_t)(r0 + lane) / (uint32_t)H;
+    const int y_l = (int)((uint32_t)(r0 + lane) - f_l * (uint32_t)H);
+    const uint32_t colbits0 = desc_column_bits(lane, W);    // of this lane's word in the first 64 words
+    unsigned long long todo = __ballot(rc_l.x != 0);
+    while (todo) {
+        int jr[EMIT_AHEAD];
+        uint32_t first[EMIT_AHEAD];
+#pragma unroll
+        for (int u = 0; u < EMIT_AHEAD; ++u) {
+            jr[u] = -1;
+            first[u] = 0u;
+            if (todo) {
+                jr[u] = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                if (lane < MW) first[u] = mask[(size_t)(r0 + jr[u]) * MW + lane];
             }
-            ++i;
-            iv += v;
         }
-        base += __builtin_amdgcn_readlane(ic, 63);
-        basev += __builtin_amdgcn_readlane(icv, 63);
-    }
+#pragma unroll
+        for (int u = 0; u < EMIT_AHEAD; ++u) {
+            if (jr[u] < 0) break;
+            const long row = r0 + jr[u];
+            const size_t f = (size_t)__builtin_amdgcn_readlane((int)f_l, jr[u]);
+            const int y = __builtin_amdgcn_readlane(y_l, jr[u]);
+            const bool yv = (y - 16 >= 0) && (y + 16 < H);
+            const uint32_t* mrow = mask + (size_t)row * MW;
+            // (frame base pointers are scalars; the keypoint index becomes a 32-bit byte offset)
+            uint8_t* const xyb = reinterpret_cast<uint8_t*>(kpxy + f * cap);
+            uint8_t* const slotb = reinterpret_cast<uint8_t*>(kpslot + f * cap);
+            int base = __builtin_amdgcn_readlane(off_l.x, jr[u]);
+            int basev = __builtin_amdgcn_readlane(off_l.y, jr[u]);
+            for (int w0 = 0; w0 < MW; w0 += 64) {
+                const int w = w0 + lane;
+                uint32_t bits = w0 == 0 ? first[u] : (w < MW ? mrow[w] : 0u);
+                const uint32_t vb = yv ? (bits & (w0 == 0 ? colbits0 : desc_column_bits(w, W))) : 0u;
+                const int c = __popc(bits), cv = __popc(vb);
+                // both counts in one scan (a row holds at most 32 * 64 corners: 16 bits each)
+                const int icc = wave_incl_scan(c | (cv << 16), lane);
+                const int ic = icc & 0xFFFF, icv = icc >> 16;
+                int i = base + ic - c, iv = basev + icv - cv;
+                while (bits) {
+                    const int b = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    const bool v = (vb >> b) & 1u;
+                    if (i < cap) {
+                        *reinterpret_cast<int2*>(xyb + (uint32_t)i * 8u) = make_int2(32 * w + b, y);
+                        *reinterpret_cast<int32_t*>(slotb + (uint32_t)i * 4u) = v ? iv : -1;
+                    }
+                    ++i;
+                    iv += v;
+                }
+                base += __builtin_amdgcn_readlane(ic, 63);
+                basev += __builtin_amdgcn_readlane(icv, 63);
+            }
+        }
     }
 }
 
