@@ -284,6 +284,10 @@ def test_c_abi_rejects_bad_arguments_and_stays_usable(gctx):
     assert L.orbamd_knn2(h, None, 4, pq, 4, po, po) == _lib.E_BADARG
     assert L.orbamd_knn2(h, pq, 4, None, 4, po, po) == _lib.E_BADARG
     assert L.orbamd_ctx_set_matcher(h, 99) == _lib.E_BADARG
+    # batch extraction: frame count and per-frame capacity limits (pointers only need to be non-null:
+    # the call must return before it touches them)
+    for frames, cap in [(0, 64), (65536, 64), (2, 0), (2, (1 << 26) + 1)]:
+        assert L.orbamd_extract_batch_dev(h, p, frames, 64, 80, cap, p, p, p, p) == _lib.E_BADARG
     fresh = _lib.Context(gctx.device)
     try:
         st = L.orbamd_fetch(fresh._h, pxy, pxy, pxy)
