@@ -935,6 +935,15 @@ __device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ i
         for (int it = 0; it < 6; ++it) pix[it] = load_tri_at(img, off + (lane_on ? (uint32_t)(5 * it * W) : 0u));
         // rows 30 .. 34: only row slot 0 is still inside the patch (the others get zero masks below)
         pix[6] = load_tri_at(img, (lane_on && rs == 0) ? off + (uint32_t)(30 * W) : off);
+    } else if (__all((xa >= 0 && xa <= W - 36) || !group_valid)) {
+        // clipped at the top or bottom edge only: whole 12-byte loads, rows outside the image read as 0
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int gy = gy0 + 5 * it;
+            const bool rowok = lane_on && rs + 5 * it < 31 && gy >= 0 && gy < H;
+            pix[it] = load_tri_at(img, rowok ? (uint32_t)(gy * W + gx) : 0u);
+            if (!rowok) { pix[it].v[0] = 0u; pix[it].v[1] = 0u; pix[it].v[2] = 0u; }
+        }
     } else {
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
