@@ -171,12 +171,15 @@ int orbamd_bgr2gray_dev(orbamd_ctx* ctx, const uint8_t* d_bgr, int frames, int H
  *   d_kp7       float32 [frames, cap, 7]
  *   d_desc      uint8   [frames, cap, 32]
  *   d_valid_idx int32   [frames, cap]
- *   d_counts    int32   [frames, 2] = (n, nv) -- the TRUE totals; when n > cap only the first
- *                                      cap keypoints (and their descriptors) are stored.
- * Rows past the counts are left untouched.  A frame with n > cap is an overflow the caller has to
- * handle (larger cap, extract again): its stored descriptors are those of the first cap keypoints,
- * i.e. fewer than min(nv, cap) rows, and the matching entry points, which take min(nv, cap) rows
- * of every frame, would read rows of such a frame that were never written. */
+ *   d_counts    int32   [frames, 2] = (n, nd): n = keypoints the frame holds (the TRUE total, may
+ *                                      exceed cap); nd = descriptor rows stored for it.
+ * Rows past the counts are left untouched.  When n <= cap, nd is the reference's descriptor count
+ * (keypoints >= 16 px from every edge, src/orb.cpp:156).  A frame with n > cap is an overflow: only
+ * its first cap keypoints are stored, nd counts the descriptors of exactly those keypoints (the
+ * first nd rows of what a larger cap would give), and every matching entry point works on those nd
+ * rows.  The caller detects it by n > cap and extracts again with a larger cap if it needs the rest.
+ * The call only enqueues work, but the first call at a given batch size (and any later, larger one)
+ * grows the context's work buffers, which waits for the stream and allocates device memory. */
 int orbamd_extract_batch_dev(orbamd_ctx* ctx, const uint8_t* d_gray, int frames, int H, int W,
                              int cap, float* d_kp7, uint8_t* d_desc, int32_t* d_valid_idx,
                              int32_t* d_counts);

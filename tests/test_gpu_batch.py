@@ -5,7 +5,7 @@ import pytest
 
 import oracle
 from conftest import make_test_image
-from visual_slam_amd import synth
+from visual_slam_amd import _lib, synth
 
 import golden_util
 
@@ -289,17 +289,58 @@ def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     m = small.match_consecutive(feat)
     small.sync()
     counts = feat.counts.cpu().numpy()
+    assert feat.overflowed() == [0, 1]
+    nvk = [int((e[2] < cap).sum()) for e in ex]                              # descriptors of the first cap keypoints
+    assert min(nvk) < cap, "the scene must put border keypoints among the first rows"
     for f in range(2):
-        assert counts[f].tolist() == [len(ex[f][0]), len(ex[f][1])]          # true totals
+        # n is the true total; the second count is the number of descriptor rows actually stored
+        assert counts[f].tolist() == [len(ex[f][0]), nvk[f]]
         kp = feat.kp7[f].cpu().numpy()
         assert np.array_equal(bits(kp), bits(ex[f][0][:cap]))                # first cap keypoints, in order
-        nv_kept = int((ex[f][2] < cap).sum())                                # descriptors of those keypoints
-        desc = feat.desc[f, :nv_kept].cpu().numpy()
-        assert np.array_equal(desc, ex[f][1][:nv_kept])
-    # matching clamps to cap rows; compare on the rows every frame certainly holds
+        desc = feat.desc[f, :nvk[f]].cpu().numpy()
+        assert np.array_equal(desc, ex[f][1][:nvk[f]])
+        assert np.array_equal(feat.valid_idx[f, :nvk[f]].cpu().numpy(), ex[f][2][:nvk[f]])
+    # matching works on exactly the stored rows: equal to the oracle on the truncated descriptor sets
+    eidx, edist = oracle.c.knn2(ex[1][1][:nvk[1]], ex[0][1][:nvk[0]])
+    for matcher in (_lib.MATCHER_MATRIX, _lib.MATCHER_VALU):
+        small.set_matcher(matcher)
+        # poison the rows behind the stored ones: a matcher that read them would pick them up
+        feat.desc[0, nvk[0]:] = torch.from_numpy(ex[1][1][:1]).to(small.device)
+        m = small.match_consecutive(feat)
+        small.sync()
+        idx, dist, good = m.pair(0, nvk[1])
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        gq, _, _ = oracle.c.ratio_filter(eidx, edist)
+        assert np.array_equal(np.nonzero(good)[0], gq)
+        _, _, _, kept = small.good_matches(feat, m)
+        assert int(kept[0]) == len(gq)
+
+
+def test_full_frame_noise_overflows_capacity_and_still_matches(eng8k):
+    eng = eng8k
+    """Uniform noise at 1080p: nearly every pixel neighbourhood is a corner candidate, far more than
+    cap = 8192 per frame.  Extraction keeps the first cap keypoints, matching runs on their
+    descriptors only, both equal to the CPU restatement cut at the same place."""
+    import torch
+    H, W = 1080, 1920
+    rng = np.random.default_rng(77)
+    frames = rng.integers(0, 256, size=(2, H, W), dtype=np.uint8)
+    cap = eng.cap
+    feat = eng.extract_batch(torch.from_numpy(frames).to(eng.device))
+    m = eng.match_consecutive(feat)
+    eng.sync()
+    counts = feat.counts.cpu().numpy()
+    ex = [oracle.c.extract_gray(f) for f in frames]
+    assert all(len(e[0]) > cap for e in ex)
     nvk = [int((e[2] < cap).sum()) for e in ex]
-    if min(nvk) == cap:
-        pytest.skip("no border keypoints among the first rows")
+    for f in range(2):
+        assert counts[f].tolist() == [len(ex[f][0]), nvk[f]]
+        kp, desc, vidx = feat.frame(f)
+        assert np.array_equal(bits(kp), bits(ex[f][0][:cap]))
+        assert np.array_equal(desc, ex[f][1][:nvk[f]]) and np.array_equal(vidx, ex[f][2][:nvk[f]])
+    eidx, edist = oracle.c.knn2(ex[1][1][:nvk[1]], ex[0][1][:nvk[0]])
+    idx, dist, _ = m.pair(0, nvk[1])
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
 
 
 def test_cross_buffer_pair_with_device_counts(eng):

@@ -182,7 +182,7 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     return ORBAMD_OK;
 }
 
-int run_emit(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int cap)
+int run_emit(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int cap, int32_t* d_counts)
 {
     CHK(ensure(c, c->kpxy, (size_t)frames * cap * sizeof(int2)));
     CHK(ensure(c, c->kpslot, (size_t)frames * cap * sizeof(int32_t)));
@@ -190,7 +190,7 @@ int run_emit(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int
     {
         Timed t(c, ORBAMD_K_EMIT);
         launch_emit(fs, (const uint32_t*)c->mask.p, (const int2*)c->rowcnt.p, (const int2*)c->rowoff.p, cap,
-                    (int2*)c->kpxy.p, (int32_t*)c->kpslot.p, c->stream);
+                    (int2*)c->kpxy.p, (int32_t*)c->kpslot.p, d_counts, c->stream);
     }
     return post_launch(c, "emit_kernel");
 }
@@ -254,7 +254,7 @@ int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
     const int n = c->h_counts[0], nv = c->h_counts[1];
     if (n > ORBAMD_MAX_CAP) return ORBAMD_E_CAPACITY;
     if (n > 0) {
-        CHK(run_emit(c, d_gray, 1, H, W, n));
+        CHK(run_emit(c, d_gray, 1, H, W, n, (int32_t*)c->counts.p));
         CHK(ensure(c, c->kp7, (size_t)n * 7 * sizeof(float)));
         CHK(ensure(c, c->desc, (size_t)n * 32));
         CHK(ensure(c, c->vidx, (size_t)n * sizeof(int32_t)));
@@ -445,7 +445,7 @@ int orbamd_detect(orbamd_ctx* c, const uint8_t* gray, int H, int W, int32_t* out
     int m = n < cap ? n : cap;
     m = m < ORBAMD_MAX_CAP ? m : ORBAMD_MAX_CAP;
     if (m > 0) {
-        CHK(run_emit(c, (const uint8_t*)c->gray.p, 1, H, W, m));
+        CHK(run_emit(c, (const uint8_t*)c->gray.p, 1, H, W, m, (int32_t*)c->counts.p));
         HIPCHK(c, hipMemcpyAsync(out_xy, c->kpxy.p, (size_t)m * sizeof(int2), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -673,7 +673,7 @@ int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, i
     CHK(check_image(H, W));
     c->have_extract = false;
     CHK(run_detect_counts(c, d_gray, frames, H, W, d_counts));
-    CHK(run_emit(c, d_gray, frames, H, W, cap));
+    CHK(run_emit(c, d_gray, frames, H, W, cap, d_counts));
     FrameSet fs{d_gray, frames, H, W};
     {
         Timed t(c, ORBAMD_K_DESCRIBE);

@@ -720,7 +720,8 @@ constexpr int EMIT_AHEAD = 4;       // rows whose mask words are fetched togethe
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                    int MW, long nrows, const int2* __restrict__ rowcnt,
                                                    const int2* __restrict__ rowoff, int cap,
-                                                   int2* __restrict__ kpxy, int32_t* __restrict__ kpslot)
+                                                   int2* __restrict__ kpxy, int32_t* __restrict__ kpslot,
+                                                   int32_t* __restrict__ counts)
 {
     // A wave owns 64 consecutive rows (of the whole batch: a band may straddle two frames).  Lane l
     // fetches the count and the offset of row l in one coalesced load each; only rows that hold a
@@ -779,6 +780,11 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
                     if (i < cap) {
                         *reinterpret_cast<int2*>(xyb + (uint32_t)i * 8u) = make_int2(32 * w + b, y);
                         *reinterpret_cast<int32_t*>(slotb + (uint32_t)i * 4u) = v ? iv : -1;
+                    } else if (i == cap) {
+                        // The first keypoint that does not fit: iv descriptor rows belong to the cap
+                        // keypoints that are stored.  The frame's second count becomes that number, so
+                        // that the matchers never read a descriptor row nobody wrote.
+                        counts[2 * f + 1] = iv;
                     }
                     ++i;
                     iv += v;
@@ -791,11 +797,11 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
 }
 
 void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
-                 int cap, int2* kpxy, int32_t* kpslot, hipStream_t s)
+                 int cap, int2* kpxy, int32_t* kpslot, int32_t* counts, hipStream_t s)
 {
     long nrows = (long)fs.frames * fs.H;
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((nrows + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS))), dim3(256), 0, s, mask, fs.H, fs.W,
-                       mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot);
+                       mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot, counts);
 }
 
 // Descriptor rows for a caller-supplied keypoint list (any order): slot = rank among keypoints

@@ -29,8 +29,10 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 // Also accumulates rowcnt[frame][y] = (corners, corners with a descriptor); rowcnt must be zero.
 void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStream_t s);
 void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_t* counts, hipStream_t s);
+// counts [frames][2] as written by launch_rowscan; a frame with more than cap keypoints gets its
+// second entry replaced by the number of descriptor rows that belong to its first cap keypoints.
 void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, const int2* rowoff,
-                 int cap, int2* kpxy, int32_t* kpslot, hipStream_t s);
+                 int cap, int2* kpxy, int32_t* kpslot, int32_t* counts, hipStream_t s);
 // Orientation (+ keypoint rows) and descriptors for keypoints listed in kpxy/kpslot.
 //   counts  [frames][2] device; keypoints processed per frame = min(counts[f][0], cap)
 //   kp7     [frames][cap][7] or NULL;  angle_out [frames][cap] or NULL

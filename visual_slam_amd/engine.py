@@ -16,7 +16,7 @@ class BatchFeatures:
     kp7: torch.Tensor        # float32 [frames, cap, 7]
     desc: torch.Tensor       # uint8   [frames, cap, 32]
     valid_idx: torch.Tensor  # int32   [frames, cap]
-    counts: torch.Tensor     # int32   [frames, 2] = (n, nv), true totals (may exceed cap)
+    counts: torch.Tensor     # int32   [frames, 2] = (n, nd): keypoints found (may exceed cap), descriptor rows stored
     cap: int
 
     @property
@@ -30,6 +30,10 @@ class BatchFeatures:
         return (self.kp7[f, :n].cpu().numpy(), self.desc[f, :nv].cpu().numpy(),
                 self.valid_idx[f, :nv].cpu().numpy())
 
+    def overflowed(self):
+        """Indices of the frames that hold more keypoints than `cap` (synchronises).  Such a frame
+        keeps its first cap keypoints and their descriptors; matching uses exactly those rows."""
+        return torch.nonzero(self.counts[:, 0] > self.cap).flatten().tolist()
 
     def view(self, a, b):
         """Frames [a, b) as views (no copies)."""
