@@ -2,13 +2,17 @@
 """Benchmark of the ORB front-end hot path: frames/sec through FAST + orientation + BRIEF + Hamming
 top-2 matching (frame f against f-1) on synthetic 1920x1080 frame batches resident in HBM.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Called directly with N > 1 (no WORLD_SIZE in the environment) it starts the second form itself, as a
+child process, before anything in this process touches the GPU, and exits with the child's status.
 
 One step = one pass of the whole path over this rank's batch of `--frames` frames (default 1000,
 ~5k keypoints each): extract every frame, match every consecutive pair, and (N > 1) receive the
 previous rank's last frame over RCCL send/recv and match the seam pair.  Ranks own contiguous
-ranges of one long sequence (weak scaling: `--frames` per GPU).
+ranges of one long sequence: `--frames` per GPU (weak scaling, the default) or `--total-frames` split
+over the ranks (strong scaling; `--preset 4k --total-frames 4000 --gpus 8` is the sharded 4K batch).
 
 Rank 0 prints ONE JSON line.  Besides the throughput it carries
   roofline      the dominant kernel's achieved rate against its bound (measured live with HIP events
@@ -49,6 +53,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: this many frames in all, cut into contiguous ranges over the ranks "
+                         "(overrides --frames)")
     ap.add_argument("--preset", default="1080p", choices=["480p", "1080p", "4k"])
     ap.add_argument("--cap", type=int, default=0, help="keypoint capacity per frame (0 = by preset)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-kernel HIP events")
@@ -61,21 +68,36 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_ranks(n):
+    """Start this script as n ranks (one per GPU) under torch.distributed.run and return its exit
+    status.  Runs before this process has imported torch or touched the GPU: the ranks are fresh
+    children, nothing is exec'ed over an initialised runtime."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
     from visual_slam_amd import synth
     from visual_slam_amd.engine import OrbEngine
-    from visual_slam_amd.scheduler import FrameRangeScheduler, unpack_boundary
+    from visual_slam_amd.scheduler import FrameRangeScheduler, partition_frames, unpack_boundary
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -84,11 +106,20 @@ def main():
     P = synth.PRESETS[args.preset]
     H, W = P["H"], P["W"]
     cap = args.cap or {"480p": 4096, "1080p": 8192, "4k": 32768}[args.preset]
-    F = args.frames
+    if args.total_frames > 0:
+        ranges = partition_frames(args.total_frames, world)
+        if min(b - a for a, b in ranges) < 2:
+            sys.exit("bench: --total-frames must give every rank at least two frames")
+        first_frame, F = ranges[rank][0], ranges[rank][1] - ranges[rank][0]
+        total_units = args.total_frames
+    else:
+        F = args.frames
+        first_frame = rank * F
+        total_units = world * F
     eng = OrbEngine(local_rank, cap=cap)
     from visual_slam_amd import _lib
     eng.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
-    gray = eng.synth_frames(F, H, W, first_frame=rank * F, cell=P["cell"], density=P["density"])
+    gray = eng.synth_frames(F, H, W, first_frame=first_frame, cell=P["cell"], density=P["density"])
     feat = eng.alloc_features(F)
     matches = eng.alloc_matches(F - 1)
     seam = eng.alloc_matches(1)
@@ -128,7 +159,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * F * args.steps / dt
+    value = total_units * args.steps / dt
+    # what the process group saw: one entry per rank (rank, local device index, device name)
+    devices = [(rank, torch.cuda.current_device(), torch.cuda.get_device_name())]
+    rccl_world = 1
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+        rccl_world = dist.get_world_size()
 
     # ---- per-kernel timing (HIP events on the launch stream), untimed for `value` ------------
     # One kernel at a time on one stream (whole batch per launch): a kernel's duration is only
@@ -274,16 +313,21 @@ def main():
             "metric": "frames/sec (FAST+BRIEF+match) @1080p" if args.preset == "1080p"
                       else "frames/sec (FAST+BRIEF+match) @%s" % args.preset,
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if args.total_frames > 0 else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d frame batch, %d frames per GPU, ~%d keypoints/frame, "
+            "config": {"workload": "synthetic %dx%d frame batch, %s, ~%d keypoints/frame, "
                                    "detect+orient+describe every frame, Hamming top-2 + ratio flag for every "
-                                   "consecutive pair" % (W, H, F, int(round(n.mean()))),
-                       "frames_per_gpu": F, "keypoints_per_frame": float(n.mean()),
+                                   "consecutive pair" % (W, H, ("%d frames in all, contiguous ranges over the ranks"
+                                                                % args.total_frames) if args.total_frames > 0
+                                                         else "%d frames per GPU" % F, int(round(n.mean()))),
+                       "frames_per_gpu": F, "total_frames": total_units, "keypoints_per_frame": float(n.mean()),
                        "descriptors_per_frame": float(nv.mean()), "capacity_per_frame": cap,
                        "matcher": args.matcher, "pipelined_frame_ranges": args.chunks,
                        "parallelism": "contiguous frame ranges, %d rank(s), RCCL send/recv of the seam frame"
                                       % world},
+            "rccl_world_size": rccl_world,
+            "rank_devices": [list(d) for d in devices],
             "roofline": rooflines.get(dominant),
             "roofline_kernel": dominant,
             "roofline_launches": "whole-batch launches, one kernel at a time" if args.chunks <= 1 else

@@ -112,14 +112,14 @@ int orbamd_detect(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
 /* ORBDescriptor::computeOrientation (reference src/orb.cpp:110-140; include/orb.hpp:17) for n
  * caller-supplied integer keypoints; angle in degrees in [0, 360] as float.  Any int32 is a legal
  * coordinate: a patch that lies outside the image has no pixels and gets angle 0, one that
- * straddles an edge is clipped (src/orb.cpp:250). */
+ * straddles an edge is clipped (src/orb.cpp:250).  n <= ORBAMD_MAX_CAP. */
 int orbamd_orient(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
                   const int32_t* xy, int n, float* angle_out);
 
 /* ORBDescriptor::computeDescriptors (reference src/orb.cpp:142-234; include/orb.hpp:20).
  * Keypoints closer than 16 px to an edge get no descriptor; desc_out receives *nv_out rows of
  * 32 bytes in keypoint order and valid_idx_out (may be NULL) the keypoint index of each row.
- * desc_out and valid_idx_out must hold n rows. */
+ * desc_out and valid_idx_out must hold n rows.  n <= ORBAMD_MAX_CAP. */
 int orbamd_describe(orbamd_ctx* ctx, const uint8_t* gray, int H, int W,
                     const int32_t* xy, const float* angle, int n,
                     uint8_t* desc_out, int32_t* valid_idx_out, int* nv_out);
@@ -215,7 +215,9 @@ int orbamd_ratio_filter_batch_dev(orbamd_ctx* ctx, const int32_t* d_idx, const u
  * counts: query frame `qframe` of (d_qdesc, d_qcounts) against train frame `tframe` of
  * (d_tdesc, d_tcounts), both with per-frame capacity `cap`.  This is the pair that spans two
  * GPUs' frame ranges: the train side is the boundary frame received from the neighbouring GPU.
- * Outputs as one pair of orbamd_knn2_batch_dev: d_idx/d_dist int32 [cap, 2], d_good uint8 [cap]. */
+ * Outputs as one pair of orbamd_knn2_batch_dev: d_idx/d_dist int32 [cap, 2], d_good uint8 [cap].
+ * The call is given no frame counts of the two buffers, so it cannot range-check qframe and
+ * tframe beyond >= 0: the caller guarantees that both frames exist. */
 int orbamd_knn2_cross_dev(orbamd_ctx* ctx, const uint8_t* d_qdesc, const int32_t* d_qcounts, int qframe,
                           const uint8_t* d_tdesc, const int32_t* d_tcounts, int tframe, int cap,
                           int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);

@@ -20,11 +20,12 @@ class OracleEngine:
         counts = torch.zeros((frames, 2), dtype=torch.int32)
         for f in range(frames):
             kp, d, v = oracle.c.extract_gray(gray[f].numpy())
-            n, nv = min(len(kp), cap), min(len(d), cap)
+            n, nv = min(len(kp), cap), int((v < cap).sum())
             kp7[f, :n] = torch.from_numpy(kp[:n])
             desc[f, :nv] = torch.from_numpy(d[:nv])
             vidx[f, :nv] = torch.from_numpy(v[:nv])
-            counts[f, 0], counts[f, 1] = len(kp), len(d)
+            # (n found, descriptor rows stored): the library's convention, also when n > cap
+            counts[f, 0], counts[f, 1] = len(kp), int((v < cap).sum())
         return BatchFeatures(kp7=kp7, desc=desc, valid_idx=vidx, counts=counts, cap=cap)
 
     def _match(self, q, t):

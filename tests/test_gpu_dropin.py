@@ -1,5 +1,7 @@
 """GPU: the drop-in surfaces -- pybind11 module `build.orb_project` (the reference's module name and
 location) and the Python host mirror of the reference's interface."""
+import importlib
+
 import numpy as np
 import pytest
 
@@ -119,3 +121,41 @@ def test_host_mirror_of_reference_interface():
     g = orb.good_matches(desc, d_prev)
     assert all(np.array_equal(a, b) for a, b in zip(g, e))
     assert [m.trainIdx for m in matcher.match(desc, d_prev)] == eidx[:, 0].tolist()
+
+
+def test_concurrent_calls_from_two_python_threads_serialise():
+    """The reference's caller runs extract on a worker thread beside a GUI thread (main.py:85-86).
+    Two threads calling into the module at once must take turns, not deadlock on the module's
+    lock and the GIL."""
+    import threading
+    orb = importlib.import_module("build.orb_project")
+    img = np.repeat(make_test_image(120, 160, 5)[:, :, None], 3, axis=2)
+    kp0, d0 = orb.extract(img)
+    assert len(d0) >= 2
+    i0, s0 = orb.knn_match2(d0, d0)
+    errors, done = [], []
+
+    def extractor():
+        try:
+            for _ in range(40):
+                kp, d = orb.extract(img)
+                assert np.array_equal(d, d0) and np.array_equal(kp.view(np.uint32), kp0.view(np.uint32))
+            done.append("e")
+        except Exception as exc:      # pragma: no cover
+            errors.append(exc)
+
+    def matcher():
+        try:
+            for _ in range(40):
+                i, s = orb.knn_match2(d0, d0)
+                assert np.array_equal(i, i0) and np.array_equal(s, s0)
+            done.append("m")
+        except Exception as exc:      # pragma: no cover
+            errors.append(exc)
+
+    ts = [threading.Thread(target=extractor, daemon=True), threading.Thread(target=matcher, daemon=True)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not errors and sorted(done) == ["e", "m"], "threads hung or failed: %r %r" % (done, errors)

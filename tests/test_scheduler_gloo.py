@@ -62,16 +62,22 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, total=TOTAL):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle_engine import OracleEngine
-        s, e = partition_frames(TOTAL, world)[rank]
-        gray = torch.from_numpy(synth.synth_frames(H, W, s, e - s, cell=CELL))
+        s, e = partition_frames(total, world)[rank]
+        gray = (torch.from_numpy(synth.synth_frames(H, W, s, e - s, cell=CELL)) if e > s
+                else torch.zeros((0, H, W), dtype=torch.uint8))
         sched = FrameRangeScheduler(OracleEngine(cap=CAP))
         assert (sched.rank, sched.world) == (rank, world)
         res = sched.process(gray, first_frame=s)
+        if res.features is None:                     # a rank without frames only relays the seam frame
+            assert e == s
+            np.savez(os.path.join(outdir, "rank%d.npz" % rank), first=s, empty=1)
+            dist.barrier()
+            return
         out = {"first": s, "counts": res.features.counts.numpy(),
                "idx": res.matches.idx.numpy(), "dist": res.matches.dist.numpy(), "good": res.matches.good.numpy()}
         if res.boundary_matches is not None:
@@ -118,3 +124,19 @@ def test_two_ranks_reproduce_the_single_process_matches(tmp_path):
         else:
             assert "b_idx" not in z.files
     assert seen_pairs == set(range(1, TOTAL))          # every consecutive pair exactly once
+
+
+@pytest.mark.timeout(180)
+def test_more_ranks_than_frames_does_not_deadlock(tmp_path):
+    """3 ranks, 2 frames: ranges (0,1), (1,2), (2,2).  The rank without frames must still take part in
+    the seam chain, or its neighbour blocks in its send."""
+    import oracle
+    world, total = 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), total), nprocs=world, join=True)
+    frames = synth.synth_frames(H, W, 0, total, cell=CELL)
+    ex = [oracle.c.extract_gray(f) for f in frames]
+    z1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    nq = len(ex[1][1])
+    eidx, edist = oracle.c.knn2(ex[1][1], ex[0][1])
+    assert np.array_equal(z1["b_idx"][0, :nq], eidx) and np.array_equal(z1["b_dist"][0, :nq], edist)
+    assert "empty" in np.load(os.path.join(str(tmp_path), "rank2.npz")).files

@@ -111,6 +111,12 @@ struct Timed {
             a = get_event(c);
             b = get_event(c);
             if (a && b) (void)hipEventRecord(a, c->stream);
+            else {
+                // no pair of events: this launch goes untimed, and a lone event goes back to the pool
+                if (a) c->pool.push_back(a);
+                if (b) c->pool.push_back(b);
+                a = b = nullptr;
+            }
         }
     }
     ~Timed()
@@ -467,7 +473,7 @@ static int upload_keypoints(orbamd_ctx* c, const uint8_t* gray, int H, int W, co
 int orbamd_orient(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int32_t* xy, int n, float* angle_out)
 {
     CHK(enter(c));
-    if (!gray || n < 0 || (n > 0 && (!xy || !angle_out))) return ORBAMD_E_BADARG;
+    if (!gray || n < 0 || n > ORBAMD_MAX_CAP || (n > 0 && (!xy || !angle_out))) return ORBAMD_E_BADARG;
     CHK(check_image(H, W));
     if (n == 0) return ORBAMD_OK;
     c->have_extract = false;
@@ -493,7 +499,8 @@ int orbamd_describe(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int3
                     int n, uint8_t* desc_out, int32_t* valid_idx_out, int* nv_out)
 {
     CHK(enter(c));
-    if (!gray || !nv_out || n < 0 || (n > 0 && (!xy || !angle || !desc_out))) return ORBAMD_E_BADARG;
+    if (!gray || !nv_out || n < 0 || n > ORBAMD_MAX_CAP || (n > 0 && (!xy || !angle || !desc_out)))
+        return ORBAMD_E_BADARG;
     CHK(check_image(H, W));
     *nv_out = 0;
     if (n == 0) return ORBAMD_OK;

@@ -30,6 +30,19 @@ namespace {
 std::mutex g_mu;
 orbamd_ctx* g_ctx = nullptr;
 
+// The module's one context is shared by all Python threads and guarded by g_mu.  The mutex is only
+// ever WAITED for with the GIL released: a thread that blocked on it while holding the GIL would
+// deadlock against the owner, which needs the GIL back at the end of its own nogil section.
+std::unique_lock<std::mutex> lock_context()
+{
+    std::unique_lock<std::mutex> lock(g_mu, std::defer_lock);
+    {
+        py::gil_scoped_release nogil;
+        lock.lock();
+    }
+    return lock;
+}
+
 orbamd_ctx* ctx()
 {
     if (!g_ctx) {
@@ -80,7 +93,7 @@ Extracted run_extract(const py::array& image, bool bgr)
 {
     py::array_t<uint8_t> img = accept_image(image, bgr);
     const int H = (int)img.shape(0), W = (int)img.shape(1);
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock = lock_context();
     orbamd_ctx* c = ctx();
     int n = 0, nv = 0, st;
     {
@@ -138,7 +151,7 @@ py::tuple knn_match2(const py::array& d1, const py::array& d2)
     using Shape = std::vector<py::ssize_t>;
     py::array_t<int32_t> idx(Shape{nq, 2});
     py::array_t<int32_t> dist(Shape{nq, 2});
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock = lock_context();
     orbamd_ctx* c = ctx();
     int st;
     {
@@ -159,7 +172,7 @@ py::tuple ratio_filter(const py::array_t<int32_t, py::array::c_style | py::array
     using Shape = std::vector<py::ssize_t>;
     py::array_t<int32_t> gq(Shape{nq}), g2(Shape{nq}), g1(Shape{nq});
     int m = 0, st;
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock = lock_context();
     orbamd_ctx* c = ctx();
     {
         py::gil_scoped_release nogil;

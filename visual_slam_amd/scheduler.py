@@ -114,10 +114,35 @@ class FrameRangeScheduler:
         reqs = dist.batch_isend_irecv(ops) if ops else []
         return reqs, rbuf
 
+    def _relay(self, device):
+        """A rank without frames keeps the seam chain intact: it passes the previous rank's boundary
+        frame on to the next rank unchanged (rank 0 without frames sends an empty frame), so its
+        neighbours' transfers complete and the next rank that has frames still matches against the
+        last frame that exists."""
+        nbytes = boundary_message_bytes(self.engine.cap, self.with_keypoints)
+        if self.rank > 0:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, self.rank - 1, self.group)]):
+                r.wait()
+        else:
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            hdr = buf[:HEADER_BYTES].view(torch.int32)
+            hdr[2] = self.engine.cap
+            hdr[3] = 1 if self.with_keypoints else 0
+        if self.rank + 1 < self.world:
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, self.rank + 1, self.group)]):
+                r.wait()
+        return buf
+
     def process(self, gray, first_frame=0):
         """gray: this rank's frames [frames, H, W].  Returns a ShardResult; all work is enqueued
-        asynchronously where the engine is asynchronous."""
+        asynchronously where the engine is asynchronous.  A rank whose range is empty (more ranks
+        than frames) returns a ShardResult without features."""
         eng = self.engine
+        if gray.shape[0] == 0:
+            if self.world > 1:
+                self._relay(gray.device)
+            return ShardResult(features=None, matches=None, first_frame=first_frame)
         feat = eng.extract_batch(gray)
         # Post the seam transfer first so it overlaps the local matching.
         reqs, rbuf = self.exchange(feat)
