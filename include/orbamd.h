@@ -226,6 +226,22 @@ int orbamd_knn2_cross_dev(orbamd_ctx* ctx, const uint8_t* d_qdesc, const int32_t
 int orbamd_knn2_dev(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                     int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
 
+/* orbamd_knn2_dev without any allocation.  No counterpart in the reference; it is for callers that
+ * cannot allocate device memory at call time: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same arguments and the same results as orbamd_knn2_dev, but the
+ * partial results of the train-axis split live in a fixed 4 MiB array inside the library (one copy
+ * per GPU, held until the process ends) instead of a context buffer that grows on demand, the split
+ * count is lowered until they fit, and nothing is timed.  The call makes no hipMalloc / hipFree and
+ * creates no events; it only enqueues kernels on the context's stream.
+ *   nq <= ORBAMD_NOALLOC_MAX_QUERIES, else ORBAMD_E_CAPACITY (text via orbamd_last_error()).
+ * All calls on one GPU share that GPU's array, from every context: calls that overlap in time on
+ * one GPU (two contexts, two streams) race on it and must be serialised by the caller.  The array
+ * keeps the previous call's contents; the kernels overwrite every slot they read, so no clearing is
+ * needed between calls. */
+#define ORBAMD_NOALLOC_MAX_QUERIES 65536
+int orbamd_knn2_dev_noalloc(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                            int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liborbamd.so")
 
 OK, E_BADARG, E_CAPACITY, E_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 MAX_TRAIN = 1 << 18
+NOALLOC_MAX_QUERIES = 65536
 K_COUNT = 10
 MATCHER_MATRIX, MATCHER_VALU = 0, 1
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "orbamd_ratio_filter_batch_dev": (_int, [_c_ctx, _vp, _vp, _vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "orbamd_knn2_cross_dev": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "orbamd_knn2_dev": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp]),
+    "orbamd_knn2_dev_noalloc": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -311,3 +313,8 @@ class Context:
     def knn2_dev(self, d_q, nq, d_t, nt, d_idx, d_dist, d_good=0):
         self._chk(lib().orbamd_knn2_dev(self._h, _vp(d_q), nq, _vp(d_t or 0), nt, _vp(d_idx), _vp(d_dist),
                                         _vp(d_good or 0)), "knn2_dev")
+
+    def knn2_dev_noalloc(self, d_q, nq, d_t, nt, d_idx, d_dist, d_good=0):
+        """knn2_dev on the library's fixed scratch array: no allocation, nq <= NOALLOC_MAX_QUERIES."""
+        self._chk(lib().orbamd_knn2_dev_noalloc(self._h, _vp(d_q), nq, _vp(d_t or 0), nt, _vp(d_idx), _vp(d_dist),
+                                                _vp(d_good or 0)), "knn2_dev_noalloc")

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -12,6 +13,14 @@
 #include "orb_internal.h"
 
 using namespace orbamd;
+
+// Scratch of orbamd_knn2_dev_noalloc: the partial top-2 keys of the train-axis split, which every
+// other matching entry point keeps in a context-owned hipMalloc buffer.  Every GPU the library runs
+// on holds its own copy of this array until the process ends.  In host code the NAME of the array is
+// only a handle for hipGetSymbolAddress; the address kernels get is looked up once per device in
+// orbamd_ctx_create (noalloc_scratch_of) and kept in the context.
+#define ORBAMD_NOALLOC_SCRATCH_BYTES (4u << 20)
+static __device__ __align__(256) unsigned char scratch[ORBAMD_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -38,6 +47,7 @@ struct orbamd_ctx {
     DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
     int matcher = ORBAMD_MATCHER_MATRIX;
     int32_t* h_counts = nullptr;  // pinned, 4 ints
+    void* noalloc_scratch = nullptr;  // device address of `scratch` on this context's GPU
 
     // state of the last single-frame extract
     bool have_extract = false;
@@ -222,13 +232,45 @@ int choose_splits(int nq, int nt, int npairs, int rows_per_block, int target)
     return (int)s;
 }
 
-int run_knn2(orbamd_ctx* c, Knn2Args& a)
+// Device address of `scratch` on `device` (which must be current), looked up once per device.
+int noalloc_scratch_of(int device, void** out)
+{
+    static std::mutex mu;
+    static void* ptr_of[64] = {nullptr};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) return ORBAMD_E_BADARG;
+    if (!ptr_of[device]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return ORBAMD_E_DEVICE;
+        ptr_of[device] = p;
+    }
+    *out = ptr_of[device];
+    return ORBAMD_OK;
+}
+
+// scratch / scratch_bytes: where the partial keys of a train-axis split go.  NULL = the context's own
+// grow-only buffer (may allocate); otherwise the given memory is used as it is, the split count is
+// lowered until it fits, and the launches are not bracketed by timing events (creating one allocates).
+int run_knn2(orbamd_ctx* c, Knn2Args& a, void* scratch_mem = nullptr, size_t scratch_bytes = 0)
 {
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     const int ntmax = a.tcounts ? a.cap : a.nt_fixed;
     const bool matrix = c->matcher == ORBAMD_MATCHER_MATRIX;
     a.splits = matrix ? choose_splits(nqmax, ntmax, a.npairs, 256, 1024)
                       : choose_splits(nqmax, ntmax, a.npairs, 256, 2048);
+    if (scratch_mem) {
+        const size_t per_split = (size_t)a.npairs * a.cap * 2 * sizeof(uint32_t);
+        while (a.splits > 1 && per_split * a.splits > scratch_bytes) --a.splits;
+        a.partial = (uint32_t*)scratch_mem;
+        if (matrix) launch_knn2_mfma(a, c->stream);
+        else launch_knn2(a, c->stream);
+        CHK(post_launch(c, matrix ? "knn2_mfma_kernel" : "knn2_kernel"));
+        if (a.splits > 1) {
+            launch_knn2_merge(a, c->stream);
+            CHK(post_launch(c, "knn2_merge_kernel"));
+        }
+        return ORBAMD_OK;
+    }
     if (a.splits > 1) {
         CHK(ensure(c, c->partial, (size_t)a.npairs * a.splits * a.cap * 2 * sizeof(uint32_t)));
         a.partial = (uint32_t*)c->partial.p;
@@ -326,6 +368,12 @@ int orbamd_ctx_create(int device, orbamd_ctx** out)
         return ORBAMD_E_DEVICE;
     }
     c->stream = c->own_stream;
+    if (noalloc_scratch_of(device, &c->noalloc_scratch) != ORBAMD_OK) {
+        (void)hipHostFree(c->h_counts);
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return ORBAMD_E_DEVICE;
+    }
     if (const char* e = getenv("ORBAMD_MATCHER"))
         if (strcmp(e, "valu") == 0) c->matcher = ORBAMD_MATCHER_VALU;
     *out = c;
@@ -774,6 +822,33 @@ int orbamd_knn2_dev(orbamd_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_
     a.dist = d_dist;
     a.good = d_good;
     return run_knn2(c, a);
+}
+
+int orbamd_knn2_dev_noalloc(orbamd_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                            int32_t* d_idx, int32_t* d_dist, uint8_t* d_good)
+{
+    CHK(enter(c));
+    if (nq < 0 || nt < 0 || nt >= ORBAMD_MAX_TRAIN) return ORBAMD_E_BADARG;
+    if (nq > ORBAMD_NOALLOC_MAX_QUERIES) {
+        c->err = "orbamd_knn2_dev_noalloc: nq exceeds ORBAMD_NOALLOC_MAX_QUERIES";
+        return ORBAMD_E_CAPACITY;
+    }
+    if (nq == 0) return ORBAMD_OK;
+    if (!d_q || !d_idx || !d_dist || (nt > 0 && !d_t)) return ORBAMD_E_BADARG;
+    if (!c->noalloc_scratch) return ORBAMD_E_STATE;
+    Knn2Args a{};
+    a.qdesc = d_q;
+    a.tdesc = d_t ? d_t : d_q;
+    a.npairs = 1;
+    a.cap = nq;
+    a.nq_fixed = nq;
+    a.nt_fixed = nt;
+    a.idx = d_idx;
+    a.dist = d_dist;
+    a.good = d_good;
+    // Every (split, query) slot of the scratch that the merge reads is written by the matcher kernel
+    // of the same call first, so nothing has to be cleared between calls.
+    return run_knn2(c, a, c->noalloc_scratch, ORBAMD_NOALLOC_SCRATCH_BYTES);
 }
 
 }  // extern "C"
