@@ -162,6 +162,12 @@ int orbamd_ratio_filter(orbamd_ctx* ctx, const int32_t* idx, const int32_t* dist
 int orbamd_synth_frames_dev(orbamd_ctx* ctx, uint8_t* d_gray, int frames, int H, int W,
                             int first_frame, uint32_t seed, int cell, int density_thr);
 
+/* The textured synthetic scene (synth_textured_frame in visual_slam_amd/synth.py): piecewise-constant
+ * texture with local contrast far above the FAST threshold, about 11 k keypoints per 1080p frame in
+ * clusters of adjacent pixels.  Measurement input; no counterpart in the reference. */
+int orbamd_synth_textured_dev(orbamd_ctx* ctx, uint8_t* d_gray, int frames, int H, int W,
+                              int first_frame, uint32_t seed);
+
 /* BGR -> gray for `frames` frames of H*W pixels (device pointers). */
 int orbamd_bgr2gray_dev(orbamd_ctx* ctx, const uint8_t* d_bgr, int frames, int H, int W,
                         uint8_t* d_gray);

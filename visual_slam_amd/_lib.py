@@ -50,6 +50,7 @@ SIGNATURES = {
     "orbamd_knn2": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp]),
     "orbamd_ratio_filter": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _vp, _intp]),
     "orbamd_synth_frames_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, ctypes.c_uint32, _int, _int]),
+    "orbamd_synth_textured_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, ctypes.c_uint32]),
     "orbamd_bgr2gray_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _vp]),
     "orbamd_extract_batch_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "orbamd_knn2_batch_dev": (_int, [_c_ctx, _vp, _vp, _int, _int, _vp, _int, _vp, _vp, _vp]),
@@ -287,6 +288,10 @@ class Context:
         self._chk(lib().orbamd_synth_frames_dev(self._h, _vp(d_gray), frames, H, W, first_frame,
                                                 ctypes.c_uint32(seed & 0xFFFFFFFF), cell, density_thr),
                   "synth_frames_dev")
+
+    def synth_textured_dev(self, d_gray, frames, H, W, first_frame, seed):
+        self._chk(lib().orbamd_synth_textured_dev(self._h, _vp(d_gray), frames, H, W, first_frame,
+                                                  ctypes.c_uint32(seed & 0xFFFFFFFF)), "synth_textured_dev")
 
     def bgr2gray_dev(self, d_bgr, frames, H, W, d_gray):
         self._chk(lib().orbamd_bgr2gray_dev(self._h, _vp(d_bgr), frames, H, W, _vp(d_gray)), "bgr2gray_dev")

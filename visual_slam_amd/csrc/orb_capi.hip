@@ -705,6 +705,19 @@ int orbamd_synth_frames_dev(orbamd_ctx* c, uint8_t* d_gray, int frames, int H, i
     return post_launch(c, "synth_kernel");
 }
 
+int orbamd_synth_textured_dev(orbamd_ctx* c, uint8_t* d_gray, int frames, int H, int W, int first_frame,
+                              uint32_t seed)
+{
+    CHK(enter(c));
+    if (!d_gray || frames <= 0 || first_frame < 0) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    {
+        Timed t(c, ORBAMD_K_SYNTH);
+        launch_synth(d_gray, frames, H, W, first_frame, seed, 0, 0, c->stream);
+    }
+    return post_launch(c, "synth_kernel");
+}
+
 int orbamd_bgr2gray_dev(orbamd_ctx* c, const uint8_t* d_bgr, int frames, int H, int W, uint8_t* d_gray)
 {
     CHK(enter(c));

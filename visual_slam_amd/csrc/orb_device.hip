@@ -181,6 +181,20 @@ __device__ __forceinline__ uint32_t synth_pixel(uint32_t x, uint32_t y, uint32_t
     return inblob ? (bright ? 230u : 10u) : bg;
 }
 
+// Textured scene (definition: synth_textured_frame in visual_slam_amd/synth.py).
+__device__ __forceinline__ uint32_t synth_textured_pixel(uint32_t x, uint32_t y, uint32_t f, uint32_t seed)
+{
+    const uint32_t wx = x + f, wy = y;
+    const uint32_t a = hash3(seed ^ 0x7E01u, wx >> 4, wy >> 4, 0u) & 255u;
+    const uint32_t b = hash3(seed ^ 0x7E02u, wx / 7u, wy / 7u, 0u) % 81u;
+    const uint32_t n = hash3(seed ^ 0x7E03u, wx, wy, 0u) % 9u;
+    uint32_t v = 30u + (a >> 1) + b + n;
+    const uint32_t hf = hash3(seed ^ 0xF11Cu, x, y, f);
+    if ((hf & 15u) == 0u) v = ((hf >> 4) & 1u) ? v + 1u : v - 1u;
+    return v;
+}
+
+// cell == 0 selects the textured scene.
 __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ gray, int frames, int H,
                                                     int W, int first_frame, uint32_t seed,
                                                     uint32_t cell, uint32_t thr)
@@ -198,7 +212,9 @@ __global__ __launch_bounds__(256) void synth_kernel(uint8_t* __restrict__ gray, 
             uint32_t f = (uint32_t)(j / per_frame);
             long r = j - (long)f * per_frame;
             uint32_t y = (uint32_t)(r / W), x = (uint32_t)(r - (long)y * W);
-            out |= synth_pixel(x, y, f + (uint32_t)first_frame, seed, cell, thr) << (8 * b);
+            const uint32_t px = cell ? synth_pixel(x, y, f + (uint32_t)first_frame, seed, cell, thr)
+                                     : synth_textured_pixel(x, y, f + (uint32_t)first_frame, seed);
+            out |= px << (8 * b);
         }
         if (al && nb == 4) *reinterpret_cast<uint32_t*>(gray + i) = out;
         else for (int b = 0; b < nb; ++b) gray[i + b] = (uint8_t)(out >> (8 * b));

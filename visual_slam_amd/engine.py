@@ -100,6 +100,11 @@ class OrbEngine:
                                   synth.density_threshold(density))
         return out
 
+    def synth_textured_frames(self, frames, H, W, first_frame=0, seed=synth.DEFAULT_SEED):
+        out = torch.empty((frames, H, W), dtype=torch.uint8, device=self.device)
+        self.ctx.synth_textured_dev(out.data_ptr(), frames, H, W, first_frame, seed)
+        return out
+
     def bgr2gray(self, bgr):
         assert bgr.dtype == torch.uint8 and bgr.dim() == 4 and bgr.shape[3] == 3 and bgr.is_contiguous()
         frames, H, W = bgr.shape[:3]

@@ -84,6 +84,34 @@ def synth_frame(H, W, frame_index, seed=DEFAULT_SEED, cell=20, density=0.386):
     return out.astype(np.uint8)
 
 
+# Textured scene: the same scrolling world, but every pixel belongs to a piecewise-constant texture
+# instead of a flat background -- 16x16 blocks of a random level in 0 .. 127, plus 7x7 blocks of a
+# random offset in 0 .. 80, plus per-pixel noise in 0 .. 8, plus the +-1 flicker.  Local contrast is
+# far above the FAST threshold everywhere, so the cheap screens reject little, corners sit on block
+# corners in clusters of adjacent pixels, and a 1080p frame holds about 11 k keypoints.
+TEX_COARSE_SHIFT, TEX_MID_CELL, TEX_MID_LEVELS, TEX_NOISE_LEVELS = 4, 7, 81, 9
+
+
+def synth_textured_frame(H, W, frame_index, seed=DEFAULT_SEED):
+    """One gray frame of the textured scene, uint8 [H, W]."""
+    f = int(frame_index)
+    y, x = np.meshgrid(np.arange(H, dtype=np.uint64), np.arange(W, dtype=np.uint64), indexing="ij")
+    wx = x + np.uint64(f)
+    wy = y
+    a = hash3(seed ^ 0x7E01, wx >> np.uint64(TEX_COARSE_SHIFT), wy >> np.uint64(TEX_COARSE_SHIFT), 0) & np.uint64(255)
+    b = hash3(seed ^ 0x7E02, wx // np.uint64(TEX_MID_CELL), wy // np.uint64(TEX_MID_CELL), 0) % np.uint64(TEX_MID_LEVELS)
+    n = hash3(seed ^ 0x7E03, wx, wy, 0) % np.uint64(TEX_NOISE_LEVELS)
+    v = np.uint64(30) + (a >> np.uint64(1)) + b + n          # 30 .. 245
+    hf = hash3(seed ^ 0xF11C, x, y, f)
+    flick = (hf & np.uint64(15)) == 0
+    v = np.where(flick, np.where((hf >> np.uint64(4)) & np.uint64(1) == 1, v + np.uint64(1), v - np.uint64(1)), v)
+    return v.astype(np.uint8)
+
+
+def synth_textured_frames(H, W, first_frame, count, seed=DEFAULT_SEED):
+    return np.stack([synth_textured_frame(H, W, first_frame + i, seed) for i in range(count)])
+
+
 def synth_frames(H, W, first_frame, count, seed=DEFAULT_SEED, cell=20, density=0.386):
     return np.stack([synth_frame(H, W, first_frame + i, seed, cell, density) for i in range(count)])
 
