@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbamd.so")
+# ORBAMD_LIB: another build of the same library (kernel experiments); default is the in-tree build
+LIB_PATH = os.environ.get("ORBAMD_LIB") or os.path.join(_HERE, "liborbamd.so")
 
 OK, E_BADARG, E_CAPACITY, E_DEVICE, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5
 MAX_TRAIN = 1 << 18
