@@ -1308,12 +1308,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                     const uint32_t ay = __float_as_uint((cy + y1r) + my);
                     const uint32_t bx = __float_as_uint((cx + x2r) + mx);
                     const uint32_t by = __float_as_uint((cy + y2r) + my);
-                    // row * 48 + column: a 24-bit multiply-add (same issue cost as shift-add) on the low
-                    // 24 bits 0x400000 + row of the row's float
-                    constexpr uint32_t PITCH_B = 4u * WIN_PITCH_DW;
-                    constexpr uint32_t IDX_BIAS = (RND_MAGIC_BITS & 0xFFFFFFu) * PITCH_B + RND_MAGIC_BITS;
-                    const uint32_t i1 = (__umul24(ay, PITCH_B) + ax) - IDX_BIAS;
-                    const uint32_t i2 = (__umul24(by, PITCH_B) + bx) - IDX_BIAS;
+                    // row * 48 + column in ONE instruction: the low 16 bits of both floats' bit patterns are
+                    // the row / column themselves (0x4B400000 has none of them set), and v_mad_legacy_u16 multiplies
+                    // and adds the low halves only and writes zeros to the upper half of its result (v_mad_u16 would
+                    // keep the destination's old upper half).
+                    static_assert(4 * WIN_PITCH_DW == 48, "the row pitch is the literal in the instruction");
+                    static_assert((RND_MAGIC_BITS & 0xFFFFu) == 0u, "row and column sit in the low 16 bits");
+                    uint32_t i1, i2;
+                    asm("v_mad_legacy_u16 %0, %1, 48, %2" : "=v"(i1) : "v"(ay), "v"(ax));
+                    asm("v_mad_legacy_u16 %0, %1, 48, %2" : "=v"(i2) : "v"(by), "v"(bx));
                     const int v1 = pb[i1], v2 = pb[i2];
                     bal[r] = __ballot(v1 < v2);
                 }
