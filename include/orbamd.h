@@ -64,6 +64,12 @@ int orbamd_ctx_destroy(orbamd_ctx* ctx);
 int orbamd_ctx_set_stream(orbamd_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream (the state after orbamd_ctx_create). */
 int orbamd_ctx_use_own_stream(orbamd_ctx* ctx);
+/* Size the context's work buffers for batches of up to `frames` frames of H x W pixels with per-frame
+ * capacity `cap` (orbamd_extract_batch_dev, and orbamd_knn2_batch_dev over the consecutive pairs of
+ * such a batch).  The `_dev` calls only enqueue work, EXCEPT that a call which needs a larger work
+ * buffer than the context holds first waits for the stream, frees the buffer and allocates a bigger
+ * one; after a reserve that covers the sizes in use that never happens.  Optional. */
+int orbamd_ctx_reserve(orbamd_ctx* ctx, int frames, int H, int W, int cap);
 /* Block until everything enqueued on the context's stream has finished. */
 int orbamd_ctx_sync(orbamd_ctx* ctx);
 /* Text of the last HIP failure seen by this context ("" if none). */

@@ -603,3 +603,25 @@ def test_describe_with_non_finite_and_huge_angles(gctx):
     edesc, evidx = oracle.c.describe(img, xy, ang)
     assert np.array_equal(vidx, evidx) and np.array_equal(desc, edesc)
     assert not desc[:3].any()
+
+
+def test_reserve_presizes_the_work_buffers(eng):
+    """After orbamd_ctx_reserve a batch call of that size finds its buffers in place; results are the
+    same as without it, and nonsense sizes are rejected."""
+    import torch
+    from visual_slam_amd.engine import OrbEngine
+    H, W = 120, 160
+    frames = np.stack([synth.synth_frame(H, W, f, cell=12) for f in range(3)])
+    e2 = OrbEngine(0, cap=512)
+    e2.ctx.reserve(3, H, W, 512)
+    f2 = e2.extract_batch(torch.from_numpy(frames).to(e2.device))
+    m2 = e2.match_consecutive(f2)
+    e2.sync()
+    for f in range(3):
+        ekp, edesc, evidx = oracle.c.extract_gray(frames[f])
+        kp, desc, vidx = f2.frame(f)
+        assert np.array_equal(bits(kp), bits(ekp)) and np.array_equal(desc, edesc) and np.array_equal(vidx, evidx)
+    with pytest.raises(_lib.OrbAmdError):
+        e2.ctx.reserve(0, H, W, 512)
+    with pytest.raises(_lib.OrbAmdError):
+        e2.ctx.reserve(3, H, W, 0)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "orbamd_ctx_destroy": (_int, [_c_ctx]),
     "orbamd_ctx_set_stream": (_int, [_c_ctx, _vp]),
     "orbamd_ctx_use_own_stream": (_int, [_c_ctx]),
+    "orbamd_ctx_reserve": (_int, [_c_ctx, _int, _int, _int, _int]),
     "orbamd_ctx_sync": (_int, [_c_ctx]),
     "orbamd_last_error": (ctypes.c_char_p, [_c_ctx]),
     "orbamd_ctx_set_matcher": (_int, [_c_ctx, _int]),
@@ -158,6 +159,10 @@ class Context:
 
     def use_own_stream(self):
         self._chk(lib().orbamd_ctx_use_own_stream(self._h), "use_own_stream")
+
+    def reserve(self, frames, H, W, cap):
+        """Allocate the work buffers for batches of this size now, so that later calls only enqueue."""
+        self._chk(lib().orbamd_ctx_reserve(self._h, int(frames), int(H), int(W), int(cap)), "reserve")
 
     def sync(self):
         self._chk(lib().orbamd_ctx_sync(self._h), "sync")

@@ -405,6 +405,28 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     return ORBAMD_OK;
 }
 
+int orbamd_ctx_reserve(orbamd_ctx* c, int frames, int H, int W, int cap)
+{
+    CHK(enter(c));
+    if (frames <= 0 || frames > 65535 || cap <= 0 || cap > ORBAMD_MAX_CAP) return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    const size_t MW = mask_words(W);
+    CHK(ensure(c, c->mask, (size_t)frames * H * MW * 4));
+    CHK(ensure(c, c->rowcnt, (size_t)frames * H * sizeof(int2)));
+    CHK(ensure(c, c->rowoff, (size_t)frames * H * sizeof(int2)));
+    CHK(ensure(c, c->kpxy, (size_t)frames * cap * sizeof(int2)));
+    CHK(ensure(c, c->kpslot, (size_t)frames * cap * sizeof(int32_t)));
+    // the matcher's partial keys, for the consecutive pairs of such a batch (either kernel family)
+    if (cap <= ORBAMD_MAX_TRAIN) {
+        const int npairs = frames > 1 ? frames - 1 : 1;
+        int splits = choose_splits(cap, cap, npairs, 256, 1024);
+        const int sv = choose_splits(cap, cap, npairs, 256, 2048);
+        splits = splits > sv ? splits : sv;
+        if (splits > 1) CHK(ensure(c, c->partial, (size_t)npairs * splits * cap * 2 * sizeof(uint32_t)));
+    }
+    return ORBAMD_OK;
+}
+
 int orbamd_ctx_set_stream(orbamd_ctx* c, void* hip_stream)
 {
     CHK(enter(c));
