@@ -84,6 +84,20 @@ const char* orbamd_last_error(orbamd_ctx* ctx);
 #define ORBAMD_MATCHER_VALU   1
 int orbamd_ctx_set_matcher(orbamd_ctx* ctx, int matcher);
 
+/* Detector EXTENSION, off by default; no counterpart in the reference, whose detector is fixed at
+ * threshold 20, 12 contiguous pixels, no wrap-around, no score and no suppression (src/orb.cpp:39,
+ * :70-96; its OpenCV call with suppression is commented out at :104-105).  Applies to every later
+ * detect / extract call of the context:
+ *   threshold 1 .. 255     circle pixel counts when >= centre + threshold or <= centre - threshold
+ *   arc       9 .. 16      contiguous circle pixels required (9 = the usual "FAST-9")
+ *   wrap      0 / 1        whether a run may continue from k = 15 to k = 0
+ *   nms       0 / 1        keep a corner only if its score (the largest threshold it would still pass)
+ *                          is strictly greater than the scores of its 8 neighbours
+ * (20, 12, 0, 0) is the reference's detector and runs its bit-exact kernel; anything else runs separate,
+ * simpler kernels and costs a byte per pixel of scratch memory.  Keypoint order, orientation and
+ * descriptors are computed as always. */
+int orbamd_ctx_set_detector(orbamd_ctx* ctx, int threshold, int arc, int wrap, int nms);
+
 /* Per-kernel timing: when enabled, every kernel launch is bracketed by HIP events on the
  * context's stream.  orbamd_ctx_timing_read() drains the stream and returns, for kernel kind k
  * (ORBAMD_K_*), the summed milliseconds and launch count since the last reset. */

@@ -60,6 +60,49 @@ def detect_mask(gray):
     return mask
 
 
+def detect_score_ext(gray, arc=12, wrap=False):
+    """Corner score of the detector EXTENSION (not in the reference, whose detector has fixed
+    parameters and no score; src/orb.cpp:39, :99-105 has the OpenCV call with a score commented out).
+
+    score(p) = the largest t for which p passes the segment test with threshold t, inclusive
+    compares as in the reference: the maximum over all runs of `arc` consecutive circle pixels
+    (runs that pass k = 15 -> 0 only when `wrap`) of the smallest |difference| in the run, all
+    brighter or all darker; 0 where no run is one-signed.  int32 [H, W], 0 in the 3-pixel border.
+    With arc = 12, wrap = False: score >= 20  <=>  detect_mask()."""
+    g = gray.astype(np.int32)
+    H, W = g.shape
+    out = np.zeros((H, W), np.int32)
+    if H < 7 or W < 7:
+        return out
+    c = g[3:H - 3, 3:W - 3]
+    d = np.stack([g[3 + dy:H - 3 + dy, 3 + dx:W - 3 + dx] - c for dx, dy in _CIRCLE])   # [16, h, w]
+    best = np.zeros(c.shape, np.int32)
+    starts = range(16) if wrap else range(16 - arc + 1)
+    for s in starts:
+        run = d[[(s + j) % 16 for j in range(arc)]]
+        best = np.maximum(best, np.maximum(run.min(axis=0), (-run).min(axis=0)))
+    out[3:H - 3, 3:W - 3] = np.maximum(best, 0)
+    return out
+
+
+def detect_ext(gray, threshold=20, arc=12, wrap=False, nms=False):
+    """Detector extension: keypoints with score >= threshold; with `nms` only those whose score is
+    strictly greater than the scores of all 8 neighbours (scores below the threshold count as 0).
+    -> (xy int32 [N,2] in scan order, score int32 [N])."""
+    sc = detect_score_ext(gray, arc, wrap)
+    sc = np.where(sc >= threshold, sc, 0)
+    keep = sc > 0
+    if nms:
+        p = np.pad(sc, 1)
+        H, W = sc.shape
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx or dy:
+                    keep &= sc > p[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    ys, xs = np.nonzero(keep)
+    return np.stack([xs, ys], axis=1).astype(np.int32), sc[ys, xs].astype(np.int32)
+
+
 def detect(gray):
     """-> xy int32 [N,2], ascending (y, x) = the reference's scan order (:51-52, :100)."""
     ys, xs = np.nonzero(detect_mask(gray))  # np.nonzero is row-major: y outer, x inner

@@ -38,6 +38,7 @@ SIGNATURES = {
     "orbamd_ctx_sync": (_int, [_c_ctx]),
     "orbamd_last_error": (ctypes.c_char_p, [_c_ctx]),
     "orbamd_ctx_set_matcher": (_int, [_c_ctx, _int]),
+    "orbamd_ctx_set_detector": (_int, [_c_ctx, _int, _int, _int, _int]),
     "orbamd_ctx_timing_enable": (_int, [_c_ctx, _int]),
     "orbamd_ctx_timing_reset": (_int, [_c_ctx]),
     "orbamd_ctx_timing_read": (_int, [_c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
@@ -170,6 +171,11 @@ class Context:
     def set_matcher(self, matcher):
         """MATCHER_MATRIX (default) or MATCHER_VALU: the kernel family used by every knn2 call."""
         self._chk(lib().orbamd_ctx_set_matcher(self._h, int(matcher)), "set_matcher")
+
+    def set_detector(self, threshold=20, arc=12, wrap=False, nms=False):
+        """Detector extension (off by default = the reference's detector): see include/orbamd.h."""
+        self._chk(lib().orbamd_ctx_set_detector(self._h, int(threshold), int(arc), 1 if wrap else 0,
+                                                1 if nms else 0), "set_detector")
 
     def timing_enable(self, on=True):
         self._chk(lib().orbamd_ctx_timing_enable(self._h, 1 if on else 0), "timing_enable")

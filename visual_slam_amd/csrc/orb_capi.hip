@@ -43,9 +43,11 @@ struct orbamd_ctx {
     std::string err;
 
     // work buffers
-    DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle;
+    DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle, score;
     DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
     int matcher = ORBAMD_MATCHER_MATRIX;
+    // detector parameters; the defaults are the reference's (src/orb.cpp:39, :70-96) and select its kernel
+    int det_thr = 20, det_arc = 12, det_wrap = 0, det_nms = 0;
     int32_t* h_counts = nullptr;  // pinned, 4 ints
     void* noalloc_scratch = nullptr;  // device address of `scratch` on this context's GPU
 
@@ -184,12 +186,16 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     CHK(ensure(c, c->rowcnt, (size_t)frames * H * sizeof(int2)));
     CHK(ensure(c, c->rowoff, (size_t)frames * H * sizeof(int2)));
     FrameSet fs{d_gray, frames, H, W};
+    const bool reference_detector = c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms;
+    if (!reference_detector) CHK(ensure(c, c->score, (size_t)frames * H * W));
     {
         Timed t(c, ORBAMD_K_FAST);
         HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
-        launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
+        if (reference_detector) launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
+        else launch_fast_ext(fs, c->det_thr, c->det_arc, c->det_wrap, c->det_nms, (uint8_t*)c->score.p,
+                             (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
     }
-    CHK(post_launch(c, "fast_mask_kernel"));
+    CHK(post_launch(c, reference_detector ? "fast_mask_kernel" : "fastx kernels"));
     {
         Timed t(c, ORBAMD_K_ROWSCAN);
         launch_rowscan(fs, (const int2*)c->rowcnt.p, (int2*)c->rowoff.p, d_counts, c->stream);
@@ -387,13 +393,23 @@ int orbamd_ctx_set_matcher(orbamd_ctx* c, int matcher)
     return ORBAMD_OK;
 }
 
+int orbamd_ctx_set_detector(orbamd_ctx* c, int threshold, int arc, int wrap, int nms)
+{
+    if (!c || threshold < 1 || threshold > 255 || arc < 9 || arc > 16) return ORBAMD_E_BADARG;
+    c->det_thr = threshold;
+    c->det_arc = arc;
+    c->det_wrap = wrap != 0;
+    c->det_nms = nms != 0;
+    return ORBAMD_OK;
+}
+
 int orbamd_ctx_destroy(orbamd_ctx* c)
 {
     if (!c) return ORBAMD_E_BADARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
-                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->idx, &c->dist, &c->good,
+                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->score, &c->q, &c->t, &c->idx, &c->dist, &c->good,
                       &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);

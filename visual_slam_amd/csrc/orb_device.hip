@@ -820,6 +820,128 @@ void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, c
                        mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot, counts);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Detector extension (opt-in, NOT the reference's detector and not on the parity path): arc length
+// 9 .. 16, runs that may wrap from k = 15 to k = 0, a threshold other than 20, and a corner score with
+// 3x3 non-maximum suppression.  The reference hard-codes 12 / no wrap / 20 and has no score
+// (src/orb.cpp:39, :70-96; the OpenCV call with suppression is commented out at :104-105).
+//
+// score(p) = largest t for which p passes the segment test with threshold t (inclusive compares) =
+// max over the allowed runs of the smallest one-signed |difference| in the run; stored as a byte, 0
+// where it is below the threshold.  Two plain kernels: the score map, then mask bits (+ the row
+// totals the ordered compaction needs) from the score map, with or without suppression.
+// ---------------------------------------------------------------------------------------------
+constexpr int FX_W = 64, FX_H = 16, FX_PITCH = FX_W + 8;
+
+__global__ __launch_bounds__(256) void fastx_score_kernel(const uint8_t* __restrict__ gray, int H, int W,
+                                                          int thr, int arc, int wrap, uint8_t* __restrict__ score,
+                                                          int ntc, int ntr)
+{
+    __shared__ uint8_t tile[(FX_H + 6) * FX_PITCH];
+    const uint32_t item = blockIdx.x;
+    const int bx = (int)(item % (uint32_t)ntc);
+    const uint32_t rest = item / (uint32_t)ntc;
+    const int by = (int)(rest % (uint32_t)ntr);
+    const size_t f = rest / (uint32_t)ntr;
+    const uint8_t* img = gray + f * H * W;
+    uint8_t* out = score + f * H * W;
+    const int x0 = bx * FX_W, y0 = by * FX_H;
+    for (int i = threadIdx.x; i < (FX_H + 6) * (FX_W + 6); i += 256) {
+        const int r = i / (FX_W + 6), c = i - r * (FX_W + 6);
+        const int y = y0 - 3 + r, x = x0 - 3 + c;
+        tile[r * FX_PITCH + c] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int nstarts = wrap ? 16 : 16 - arc + 1;
+    constexpr int dxk[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int dyk[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    for (int rr = 0; rr < FX_H / 4; ++rr) {
+        const int r = ty * (FX_H / 4) + rr;
+        const int x = x0 + tx, y = y0 + r;
+        if (x >= W || y >= H) continue;
+        int best = 0;
+        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
+            const uint8_t* c = tile + (r + 3) * FX_PITCH + tx + 3;
+            const int p = c[0];
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = (int)c[dyk[k] * FX_PITCH + dxk[k]] - p;
+            // any run of >= 9 holds two neighbouring compass points (k = 0, 4, 8, 12) of its sign
+            const bool b0 = d[0] >= thr, b4 = d[4] >= thr, b8 = d[8] >= thr, b12 = d[12] >= thr;
+            const bool k0 = d[0] <= -thr, k4 = d[4] <= -thr, k8 = d[8] <= -thr, k12 = d[12] <= -thr;
+            if ((b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) ||
+                (k12 && k0)) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s < nstarts) {
+                        int mb = 255, md = 255;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            if (j < arc) {
+                                const int dd = d[(s + j) & 15];
+                                mb = mb < dd ? mb : dd;
+                                md = md < -dd ? md : -dd;
+                            }
+                        }
+                        const int m = mb > md ? mb : md;
+                        best = best > m ? best : m;
+                    }
+                }
+            }
+            if (best < thr) best = 0;
+        }
+        out[(size_t)y * W + x] = (uint8_t)best;
+    }
+}
+
+// One thread per mask word: bit b = pixel 32 w + b kept.  Also adds the word's (corners, corners
+// with a descriptor) to the row totals (rowcnt zeroed before the launch).
+__global__ __launch_bounds__(256) void fastx_mask_kernel(const uint8_t* __restrict__ score, int H, int W, int MW,
+                                                         int nms, long nwords, uint32_t* __restrict__ mask,
+                                                         unsigned long long* __restrict__ rowcnt)
+{
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= nwords) return;
+    const int w = (int)(id % MW);
+    const long row = id / MW;                         // f * H + y
+    const int y = (int)(row % H);
+    const uint8_t* sc = score + (row - y) * (long)W;  // the frame's score map
+    uint32_t bits = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int x = 32 * w + b;
+        if (x >= W) break;
+        const int s = sc[(long)y * W + x];
+        bool keep = s > 0;
+        if (keep && nms) {
+            for (int dy = -1; dy <= 1 && keep; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W && (int)sc[(long)yy * W + xx] >= s) keep = false;
+                }
+        }
+        if (keep) bits |= 1u << b;
+    }
+    mask[id] = bits;
+    if (bits) {
+        const bool yv = (y - 16 >= 0) && (y + 16 < H);
+        const uint32_t v = yv ? (uint32_t)__popc(bits & desc_column_bits(w, W)) : 0u;
+        atomicAdd(rowcnt + row, (unsigned long long)(uint32_t)__popc(bits) | ((unsigned long long)v << 32));
+    }
+}
+
+void launch_fast_ext(const FrameSet& fs, int thr, int arc, int wrap, int nms, uint8_t* score, uint32_t* mask,
+                     int2* rowcnt, hipStream_t s)
+{
+    const int ntc = (fs.W + FX_W - 1) / FX_W, ntr = (fs.H + FX_H - 1) / FX_H;
+    hipLaunchKernelGGL(fastx_score_kernel, dim3((unsigned)((size_t)ntc * ntr * fs.frames)), dim3(256), 0, s, fs.gray,
+                       fs.H, fs.W, thr, arc, wrap, score, ntc, ntr);
+    const int MW = mask_words(fs.W);
+    const long nwords = (long)fs.frames * fs.H * MW;
+    hipLaunchKernelGGL(fastx_mask_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, score, fs.H, fs.W,
+                       MW, nms, nwords, mask, reinterpret_cast<unsigned long long*>(rowcnt));
+}
+
 // Descriptor rows for a caller-supplied keypoint list (any order): slot = rank among keypoints
 // that pass the 16-px border filter.  One workgroup walks the list in chunks of 1024.
 __global__ __launch_bounds__(1024) void slots_kernel(const int2* __restrict__ kpxy, int n, int H, int W,
