@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line.  Besides the throughput it carries
                 results bit for bit.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,6 +39,10 @@ INT_VALU_PEAK_TOPS = 78.6
 # What the matcher's own instruction mix (v_xor_b32 + v_bcnt_u32_b32, 1:1) sustains in a register-only
 # loop on MI355X (visual_slam_amd/csrc/micro/valu_peak.hip): v_bcnt_u32_b32 issues at half rate.
 INT_VALU_MEASURED_MIX_TOPS = 49.2
+# Vector issue: 1 024 SIMDs, one wave-instruction per SIMD every 4 cycles at 2.4 GHz.  (Measured on
+# MI355X, visual_slam_amd/csrc/micro/valu_rates.hip: three-operand, 64-bit, conversion, SAD/dot and DPP
+# instructions hold this rate; plain 32-bit VOP1/VOP2 adds, logic and moves issue in about 2.3 cycles.)
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0
 # Dense FP4 matrix-core peak (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4): 256 CUs x 4 SIMDs
 # x 4096 FLOP/clk x 2.4 GHz.
 MFMA_FP4_PEAK_TFLOPS = 10066.0
@@ -226,8 +231,9 @@ def main():
     # HBM traffic per launch from rocprofv3 PMC passes of this same workload (FETCH_SIZE and WRITE_SIZE
     # collected separately, FETCH_SIZE doubled where the kernel streams with 16-byte loads, as the
     # gfx950 notes prescribe); produced by scripts/collect_traffic.py, valid for the default workload.
-    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r01_pmc_traffic_1080p_1000frames.json")
+    tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                           "r*_pmc_traffic_1080p_1000frames.json")))
+    traffic_file = tfiles[-1] if tfiles else ""          # the latest round's measurement
     if args.preset == "1080p" and F == 1000 and os.path.exists(traffic_file):
         pmc = json.load(open(traffic_file))
         for name, key in (("fast_mask", "fast_mask_kernel"),
@@ -236,6 +242,24 @@ def main():
                           ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
             if name in rooflines and key in pmc:
                 rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+    # Vector-instruction issue beside the HBM figure for the extraction kernels: they are bound by what
+    # they issue, not by bytes.  Wave-instructions per launch from an SQ_INSTS_VALU pass of the same
+    # workload (scripts/pmc_insts.sh); peak = one wave-instruction per SIMD every four cycles.
+    ifiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                           "r*_pmc_instruction_mix_1080p_1000frames.json")))
+    if args.preset == "1080p" and F == 1000 and ifiles:
+        mix = json.load(open(ifiles[-1]))
+        for name, key in (("fast_mask", "fast_mask_kernel"), ("emit", "emit_kernel"),
+                          ("orient_describe", "orient_describe_kernel"),
+                          ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
+            if name in rooflines and key in mix and "SQ_INSTS_VALU" in mix[key]:
+                insts = mix[key]["SQ_INSTS_VALU"]
+                rate = insts / (rooflines[name]["avg_ms"] / 1e3)
+                rooflines[name]["valu_issue"] = {
+                    "bound": "valu_issue", "wave_insts_per_launch": insts, "achieved": rate / 1e9,
+                    "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                    "frac": rate / 1e9 / VALU_ISSUE_PEAK_GINST,
+                    "per_keypoint": insts / max(1.0, float(n.sum())) if name == "orient_describe" else None}
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
 
     # ---- the same steps with the XOR/popcount matcher on the vector ALUs (reported beside `value`) --
