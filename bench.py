@@ -70,6 +70,12 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=1,
                     help="frame ranges per step whose extraction / matching are pipelined on two streams "
                          "(1 = off, the default: measured 1 %% slower than whole-batch launches at 4 ranges)")
+    ap.add_argument("--workload", default="frames", choices=["frames", "dense-match"],
+                    help="frames: the headline path on synthetic frame batches.  dense-match: the matching stress "
+                         "case only -- per rank `--sets` descriptor sets of `--set-size` rows, every consecutive pair "
+                         "matched (20k x 20k Hamming top-2 per pair by default); pairs are independent, ranks share nothing")
+    ap.add_argument("--sets", type=int, default=65, help="dense-match: descriptor sets per GPU (pairs = sets - 1)")
+    ap.add_argument("--set-size", type=int, default=20000, help="dense-match: rows per descriptor set")
     ap.add_argument("--matcher", default="matrix", choices=["matrix", "valu"],
                     help="Hamming top-2 kernel family: matrix cores (default) or XOR/popcount on the vector ALUs")
     return ap.parse_args()
@@ -91,6 +97,90 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def dense_match(args, rank, local_rank, world):
+    """The dense matching stress case: `sets - 1` independent pairs of set_size x set_size BRIEF-256
+    Hamming top-2 per rank and step, descriptor sets resident in HBM (i.i.d. bytes, 1 % duplicated rows so
+    that exact distance ties occur).  One JSON line from rank 0, same contract as the frame workload."""
+    import torch
+    import torch.distributed as dist
+    from visual_slam_amd import _lib, synth
+    from visual_slam_amd.engine import BatchFeatures, OrbEngine
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    S, N = args.sets, args.set_size
+    eng = OrbEngine(local_rank, cap=N)
+    eng.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
+    host = np.stack([synth.synth_descriptors(N, 12345 + rank * S + i) for i in range(S)])
+    desc = torch.from_numpy(host).to(eng.device)
+    counts = torch.tensor([[N, N]] * S, dtype=torch.int32, device=eng.device)
+    feat = BatchFeatures(kp7=None, desc=desc, valid_idx=None, counts=counts, cap=N)
+    matches = eng.alloc_matches(S - 1, N)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.match_consecutive(feat, out=matches)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.match_consecutive(feat, out=matches)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.ctx.timing_enable(True)
+    eng.ctx.timing_reset()
+    for _ in range(max(1, args.profile_steps)):
+        eng.match_consecutive(feat, out=matches)
+    torch.cuda.synchronize()
+    timing = eng.ctx.timing_read()
+    eng.ctx.timing_enable(False)
+    ms = sum(timing[k][0] for k in ("knn2", "knn2_merge")) / max(1, timing["knn2"][1])
+    if args.matcher == "valu":
+        ach, peak, unit, bound = 16.0 * N * N * (S - 1) / (ms / 1e3) / 1e12, INT_VALU_PEAK_TOPS, "Tintop/s", "int_valu"
+    else:
+        ach, peak, unit, bound = 512.0 * N * N * (S - 1) / (ms / 1e3) / 1e12, MFMA_FP4_PEAK_TFLOPS, "TFLOP/s", "mfma"
+    roof = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "avg_ms": ms, "kernel": "knn2 (+ merge of the train-axis split)"}
+    cpu = check = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import oracle
+        oracle.c.lib()
+        nqs = min(N, 2000)                      # a slice of one pair's queries against the full train set
+        t0 = time.perf_counter()
+        eidx, edist = oracle.c.knn2(host[1][:nqs], host[0])
+        cdt = time.perf_counter() - t0
+        cpu = {"value": (nqs / N) / cdt, "unit": "frame pairs/s", "cores": 1, "kind": "port",
+               "sample": "%d of the %d queries of one pair against all %d train rows, oracle/orb_oracle.c, "
+                         "single thread; value scaled to whole pairs" % (nqs, N, N)}
+        idx, dst, _ = matches.pair(0, nqs)
+        check = bool(np.array_equal(idx, eidx) and np.array_equal(dst, edist))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frame pairs/sec (dense matching stress, %dk x %dk BRIEF-256 Hamming top-2)" % (N // 1000, N // 1000),
+            "value": world * (S - 1) * args.steps / dt, "unit": "frame pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "dense matching stress: %d pairs of %d x %d descriptors per GPU and step, top-2 + "
+                                   "ratio flag; pairs are independent, no exchange between ranks" % (S - 1, N, N),
+                       "pairs_per_gpu": S - 1, "set_size": N, "matcher": args.matcher,
+                       "parallelism": "%d rank(s), independent pairs" % world},
+            "roofline": roof, "roofline_kernel": "knn2", "cpu_baseline": cpu, "gpu_matches_cpu_on_sample": check}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if check is False:
+        sys.exit("bench: GPU results differ from the CPU restatement on the sample")
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +189,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
     args.gpus = world
+    if args.workload == "dense-match":
+        return dense_match(args, rank, local_rank, world)
 
     import torch
     import torch.distributed as dist
