@@ -237,17 +237,18 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 //
 // A pixel with its radius-3 circle inside the image is a corner iff 12 consecutive circle pixels
 // k = s .. s+11, s in 0..4 (the reference's run counter never wraps past k = 15), are all
-// >= centre + 20 or all <= centre - 20.  Every such run contains k = 4 and k = 8 and one of k = 0 /
-// k = 12, so it contains an opposite compass pair: (N and S) or (E and W) of one class.  That is
-// the cheap screen used here; it is implied by the reference's own four-point pre-test (:65-68),
-// so screening with it cannot lose a corner.
+// >= centre + 20 or all <= centre - 20.  Every such run contains k = 4 .. 11, hence k = 4 (E) and
+// k = 8 (S), and it contains k = 0 (N) when s = 0 and k = 12 (W) when s >= 1.  So a corner needs
+// E and S and (N or W) of one class.  That is the cheap screen used here; it follows from the run rule
+// alone, so screening with it cannot lose a corner (it is stronger than the reference's own
+// four-point pre-test, src/orb.cpp:65-68, which the run rule implies as well).
 //
 // Tile: 256 x 64 outputs per 256-thread workgroup, staged in LDS with a 3-row halo above and below
 // and a 16-byte margin left and right (which holds the 3 halo columns).  A wave owns a strip of 16
 // rows and walks it in two passes of 8; a lane owns one dword = 4 horizontally adjacent pixels.
 //   Phase 1, per dword: v_sad_u8 gives sum |N_k - C_k| over the dword's 4 pixels; a pixel can only
-//     pass the compass screen through (N, S) if that sum and the S sum are both >= 20, likewise
-//     (E, W).  One max/min/compare decides for 4 pixels; passing dwords are pushed to list A.
+//     pass the compass screen if the E sum and the S sum and one of the N / W sums are >= 20.
+//     Two ors, one and, one compare decide for 4 pixels; passing dwords are pushed to list A.
 //   Phase 2a, per listed dword (one per lane): the compass screen proper, per byte position with
 //     SDWA byte selects; results are 64-bit lane masks combined on the scalar unit; passing
 //     pixels are pushed to list B.  Skipped when list A is short: its pixels go straight to 2b.
@@ -293,7 +294,7 @@ __device__ __forceinline__ constexpr int circ_off(int k)
         ORB_CMP_GE_BYTE(K, be_, E, hi_); ORB_CMP_GE_BYTE(K, bw_, Wd, hi_);          \
         ORB_CMP_LE_BYTE(K, dn_, N, lo_); ORB_CMP_LE_BYTE(K, ds_, S, lo_);           \
         ORB_CMP_LE_BYTE(K, de_, E, lo_); ORB_CMP_LE_BYTE(K, dw_, Wd, lo_);          \
-        cand = (bn_ & bs_) | (be_ & bw_) | (dn_ & ds_) | (de_ & dw_);               \
+        cand = (be_ & bs_ & (bn_ | bw_)) | (de_ & ds_ & (dn_ | dw_));                \
     }
 
 constexpr int FT_LIST_A = 576;   // entries of list A per wave (resolved before a pass could overflow it)
@@ -520,8 +521,8 @@ __device__ __forceinline__ void fast_screen_rows(const uint32_t* tile32, uint16_
         }
         // sv[i] = SAD of tile rows r0 + i and r0 + i + 3, minus 20 (the accumulator input of v_sad_u8
         // starts at -20): the north term of output row i and the south term of output row i - 3.
-        // A term is negative iff its SAD is below 20, so "(N and S pass) or (E and W pass)" is the
-        // sign of (n | s) & (e | w) being clear: or / and issue at twice the rate of min / max.
+        // A term is negative iff its SAD is below 20, so "E and S and (N or W) pass" is the sign of
+        // e | s | (n & w) being clear: or / and issue at twice the rate of min / max.
         int sv[FT_EVAL_ROWS + 3];
 #pragma unroll
         for (int i = 0; i < FT_EVAL_ROWS + 3; ++i) sv[i] = (int)__builtin_amdgcn_sad_u8(rw[i], rw[i + 3], (uint32_t)-20);
@@ -531,7 +532,7 @@ __device__ __forceinline__ void fast_screen_rows(const uint32_t* tile32, uint16_
             const uint32_t C = rw[rr + 3];
             const int se = (int)__builtin_amdgcn_sad_u8(e[rr], C, (uint32_t)-20);
             const int sw = (int)__builtin_amdgcn_sad_u8(w[rr], C, (uint32_t)-20);
-            m[rr] = __ballot(((sv[rr] | sv[rr + 3]) & (se | sw)) >= 0);
+            m[rr] = __ballot((se | sv[rr + 3] | (sv[rr] & sw)) >= 0);
         }
 #pragma unroll
         for (int rr = 0; rr < FT_EVAL_ROWS; ++rr)
