@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--first", type=int, default=100000, help="index of the first synthetic frame")
     ap.add_argument("--batch", type=int, default=200)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--scene", default="sparse", choices=["sparse", "textured"],
+                    help="sparse: the benchmark scene; textured: synth_textured_frame (about twice the keypoints)")
     ap.add_argument("--chunks", type=int, default=3, help="frame ranges pipelined on two streams (1 = off)")
     args = ap.parse_args()
     import torch
@@ -29,7 +31,7 @@ def main():
     from visual_slam_amd.engine import OrbEngine
     P = synth.PRESETS[args.preset]
     H, W = P["H"], P["W"]
-    cap = {"480p": 4096, "1080p": 8192, "4k": 32768}[args.preset]
+    cap = {"480p": 4096, "1080p": 8192, "4k": 32768}[args.preset] * (2 if args.scene == "textured" else 1)
     eng = OrbEngine(0, cap=cap)
     oracle.c.lib()
     bad = 0
@@ -38,7 +40,10 @@ def main():
     with ThreadPoolExecutor(args.threads) as pool:
         while done < args.frames:
             B = min(args.batch, args.frames - done)
-            gray = eng.synth_frames(B, H, W, first_frame=args.first + done, cell=P["cell"], density=P["density"])
+            if args.scene == "textured":
+                gray = eng.synth_textured_frames(B, H, W, first_frame=args.first + done)
+            else:
+                gray = eng.synth_frames(B, H, W, first_frame=args.first + done, cell=P["cell"], density=P["density"])
             feat = eng.alloc_features(B)
             matches = eng.alloc_matches(B - 1)
             eng.extract_and_match(gray, feat, matches, chunks=args.chunks)
