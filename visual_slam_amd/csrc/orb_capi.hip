@@ -263,7 +263,7 @@ int run_knn2(orbamd_ctx* c, Knn2Args& a, void* scratch_mem = nullptr, size_t scr
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     const int ntmax = a.tcounts ? a.cap : a.nt_fixed;
     const bool matrix = c->matcher == ORBAMD_MATCHER_MATRIX;
-    a.splits = matrix ? choose_splits(nqmax, ntmax, a.npairs, 256, 1024)
+    a.splits = matrix ? choose_splits(nqmax, ntmax, a.npairs, 512, 1024)
                       : choose_splits(nqmax, ntmax, a.npairs, 256, 2048);
     if (scratch_mem) {
         const size_t per_split = (size_t)a.npairs * a.cap * 2 * sizeof(uint32_t);
@@ -436,7 +436,7 @@ int orbamd_ctx_reserve(orbamd_ctx* c, int frames, int H, int W, int cap)
     // the matcher's partial keys, for the consecutive pairs of such a batch (either kernel family)
     if (cap <= ORBAMD_MAX_TRAIN) {
         const int npairs = frames > 1 ? frames - 1 : 1;
-        int splits = choose_splits(cap, cap, npairs, 256, 1024);
+        int splits = choose_splits(cap, cap, npairs, 512, 1024);
         const int sv = choose_splits(cap, cap, npairs, 256, 2048);
         splits = splits > sv ? splits : sv;
         if (splits > 1) CHK(ensure(c, c->partial, (size_t)npairs * splits * cap * 2 * sizeof(uint32_t)));

@@ -1748,58 +1748,26 @@ __device__ __forceinline__ uint32_t knn2_decode_key(float f, int tiles, int row0
 
 constexpr int KNN2_RUN_TILES = 256;   // 8192 rows: the index field of a float key must stay below 2.0
 
-// QT query tiles (32 queries each) per wave, 4 waves per workgroup; the train tiles stream
-// through a double-buffered 4 KiB LDS tile shared by the 4 waves.
-// At least two workgroups per CU (<= 256 registers per lane): with that bound the compiler keeps
-// the accumulators in ordinary VGPRs, which the top-2 instructions can read directly.
+// One wave's share of a workgroup: QT query tiles (32 queries each) -- tiles qtile_first,
+// qtile_first + 4, ... (the four waves of a workgroup take the query tiles of their block round-robin)
+// -- against the train tiles tbeg .. tend, which stream through a double-buffered 4 KiB LDS tile
+// shared by the 4 waves.  A wave without queries (has_queries == false, QT == 1) only helps staging.
 template <int QT, bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __restrict__ qdesc,
-                                                        const uint8_t* __restrict__ tdesc,
-                                                        const int32_t* __restrict__ qcounts,
-                                                        const int32_t* __restrict__ tcounts,
-                                                        const int32_t* __restrict__ pairs, int qframe0,
-                                                        int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
-                                                        int splits, int nbp, uint32_t* __restrict__ partial,
-                                                        int32_t* __restrict__ idx, int32_t* __restrict__ dist,
-                                                        uint8_t* __restrict__ good)
+__device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32_t* __restrict__ qrows,
+                                               const uint32_t* __restrict__ trows, int nq, int nt,
+                                               int qtile_first, bool wave_has_queries, int splits, int zsplit,
+                                               int pair, int cap, uint32_t* __restrict__ partial,
+                                               int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                               uint8_t* __restrict__ good)
 {
-    __shared__ uint4 stage[2][256];
-
-    int pair, zsplit, qblk;
-    {
-        const uint32_t logical = xcd_contiguous_item();
-        const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
-        pair = (int)(logical / per_pair);
-        const uint32_t rem = logical - (uint32_t)pair * per_pair;
-        zsplit = (int)(rem / (uint32_t)nbp);
-        qblk = (int)(rem - (uint32_t)zsplit * (uint32_t)nbp);
-    }
-    int nq = nq_fixed, nt = nt_fixed, qf = 0, tf = 0;
-    if (qcounts) {
-        if (pairs) {
-            qf = pairs[2 * pair]; tf = pairs[2 * pair + 1];
-            // a pair that names a frame outside the batch is skipped (uniform over the workgroup)
-            if ((unsigned)qf >= (unsigned)nframes || (unsigned)tf >= (unsigned)nframes) return;
-        } else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
-        nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
-        nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
-    }
-    if (qblk * (128 * QT) >= nq) return;              // uniform over the workgroup
-
-    const int lane = lane_id(), wave = wave_id();
+    const int lane = lane_id();
     const int h = lane >> 5;
-    const int qtile0 = (qblk * 4 + wave) * QT;
-    const bool wave_has_queries = qtile0 * 32 < nq;   // waves without queries only help staging
-
-    // descriptor rows of this pair, 8 dwords each (rows past the counts are never read)
-    const uint32_t* __restrict__ qrows = reinterpret_cast<const uint32_t*>(qdesc) + (size_t)qf * cap * 8;
-    const uint32_t* __restrict__ trows = reinterpret_cast<const uint32_t*>(tdesc) + (size_t)tf * cap * 8;
 
     // query operands: lane (h, r) of k-step ks holds dword 2 ks + h of query row r as 32 FP4 values
     v8i b[QT][4];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
-        const int qrow = (qtile0 + u) * 32 + (lane & 31);
+        const int qrow = (qtile_first + 4 * u) * 32 + (lane & 31);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint32_t w = qrow < nq ? qrows[(size_t)qrow * 8 + 2 * ks + h] : 0u;
@@ -1927,7 +1895,7 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
         const uint32_t p2 = (uint32_t)__shfl_xor((int)k2[u], 32);
         top2_insert(k1[u], k2[u], p1);
         top2_insert(k1[u], k2[u], p2);
-        const int qi = (qtile0 + u) * 32 + (lane & 31);
+        const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
         if (h == 0 && qi < nq) {
             if (PARTIAL) {
                 const size_t o = (((size_t)pair * splits + zsplit) * cap + qi);
@@ -1937,6 +1905,71 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint8_t* __rest
             }
         }
     }
+}
+
+// Up to QTMAX query tiles per wave, 4 waves per workgroup: a workgroup owns a block of 128 * QTMAX
+// queries.  More tiles per wave mean more matrix work per staged train tile and per barrier
+// (QTMAX = 4 against 2: 2.12 against 2.22 ms per 1000 1080p frames on MI355X, at 167 registers and
+// 3 waves per SIMD), but a coarser block: the last block of a pair is mostly empty.  So the query
+// tiles of a block are dealt to the waves round-robin and every wave runs the instantiation for the
+// number of tiles it really has; the waves of the last block then all work, each on fewer tiles,
+// instead of one wave working on four.  (All waves pass the same barriers: the train loop is the same
+// in every instantiation.)
+// Three waves per SIMD (<= 168 registers per lane); the compiler keeps the
+// accumulators in ordinary VGPRs, which the top-2 instructions can read directly.
+template <int QTMAX, bool PARTIAL>
+__global__ __launch_bounds__(256, 3) void knn2_mfma_kernel(const uint8_t* __restrict__ qdesc,
+                                                        const uint8_t* __restrict__ tdesc,
+                                                        const int32_t* __restrict__ qcounts,
+                                                        const int32_t* __restrict__ tcounts,
+                                                        const int32_t* __restrict__ pairs, int qframe0,
+                                                        int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
+                                                        int splits, int nbp, uint32_t* __restrict__ partial,
+                                                        int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                        uint8_t* __restrict__ good)
+{
+    __shared__ uint4 stage[2][256];
+
+    int pair, zsplit, qblk;
+    {
+        const uint32_t logical = xcd_contiguous_item();
+        const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
+        pair = (int)(logical / per_pair);
+        const uint32_t rem = logical - (uint32_t)pair * per_pair;
+        zsplit = (int)(rem / (uint32_t)nbp);
+        qblk = (int)(rem - (uint32_t)zsplit * (uint32_t)nbp);
+    }
+    int nq = nq_fixed, nt = nt_fixed, qf = 0, tf = 0;
+    if (qcounts) {
+        if (pairs) {
+            qf = pairs[2 * pair]; tf = pairs[2 * pair + 1];
+            // a pair that names a frame outside the batch is skipped (uniform over the workgroup)
+            if ((unsigned)qf >= (unsigned)nframes || (unsigned)tf >= (unsigned)nframes) return;
+        } else { qf = pair + 1 + qframe0; tf = pair + tframe0; }
+        nq = qcounts[2 * qf + 1]; nq = nq < cap ? nq : cap;
+        nt = tcounts[2 * tf + 1]; nt = nt < cap ? nt : cap;
+    }
+    if (qblk * (128 * QTMAX) >= nq) return;           // uniform over the workgroup
+
+    const int wave = wave_id();
+    // descriptor rows of this pair, 8 dwords each (rows past the counts are never read)
+    const uint32_t* __restrict__ qrows = reinterpret_cast<const uint32_t*>(qdesc) + (size_t)qf * cap * 8;
+    const uint32_t* __restrict__ trows = reinterpret_cast<const uint32_t*>(tdesc) + (size_t)tf * cap * 8;
+    // this wave's query tiles: qtile_first + 4 u for u < nu
+    const int qtile_first = qblk * (4 * QTMAX) + wave;
+    const int qtiles = (nq + 31) >> 5;
+    int nu = (qtiles - qtile_first + 3) >> 2;
+    nu = nu < 0 ? 0 : (nu > QTMAX ? QTMAX : nu);
+#define ORB_KNN2_WAVE(N, HAS)                                                                                  \
+    knn2_mfma_wave<N, PARTIAL>(stage, qrows, trows, nq, nt, qtile_first, HAS, splits, zsplit, pair, cap, partial, \
+                               idx, dist, good)
+    static_assert(QTMAX == 4 || QTMAX == 2, "instantiations below");
+    if (nu == QTMAX) ORB_KNN2_WAVE(QTMAX, true);
+    else if (nu == 0) ORB_KNN2_WAVE(1, false);
+    else if (nu == 1) ORB_KNN2_WAVE(1, true);
+    else if (QTMAX == 4 && nu == 2) ORB_KNN2_WAVE(2, true);
+    else ORB_KNN2_WAVE(3, true);
+#undef ORB_KNN2_WAVE
 }
 
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ qcounts,
@@ -2102,7 +2135,7 @@ void launch_knn2(const Knn2Args& a, hipStream_t s)
 
 void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
 {
-    constexpr int QT = 2;
+    constexpr int QT = 4;
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     const int nbp = ((nqmax + 128 * QT - 1) / (128 * QT)) | 1;   // odd: see xcd_contiguous_item()
     dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
