@@ -22,10 +22,14 @@ def main():
     ap.add_argument("--preset", default="1080p")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--cap", type=int, default=8192)
+    ap.add_argument("--scene", default="sparse", choices=["sparse", "textured"])
     a = ap.parse_args()
     P = synth.PRESETS[a.preset]
     eng = OrbEngine(0, cap=a.cap)
-    gray = eng.synth_frames(a.frames, P["H"], P["W"], cell=P["cell"], density=P["density"])
+    if a.scene == "textured":
+        gray = eng.synth_textured_frames(a.frames, P["H"], P["W"])
+    else:
+        gray = eng.synth_frames(a.frames, P["H"], P["W"], cell=P["cell"], density=P["density"])
     feat = eng.alloc_features(a.frames)
     m = eng.alloc_matches(a.frames - 1)
     for _ in range(2):

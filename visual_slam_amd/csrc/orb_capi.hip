@@ -782,12 +782,18 @@ int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, i
     CHK(run_detect_counts(c, d_gray, frames, H, W, d_counts));
     CHK(run_emit(c, d_gray, frames, H, W, cap, d_counts));
     FrameSet fs{d_gray, frames, H, W};
+    static const bool per_keypoint = getenv("ORBAMD_DESCRIBE_PER_KEYPOINT") != nullptr;
+    const bool tiles = !per_keypoint && (W & 15) == 0 && ((uintptr_t)d_gray & 15) == 0;
     {
         Timed t(c, ORBAMD_K_DESCRIBE);
-        launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
-                               d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
+        if (tiles)
+            launch_describe_tiles(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap,
+                                  (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, c->stream);
+        else
+            launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
+                                   d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
     }
-    return post_launch(c, "orient_describe_kernel");
+    return post_launch(c, tiles ? "describe_tile_kernel" : "orient_describe_kernel");
 }
 
 int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int frames, int cap,

@@ -1495,6 +1495,269 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile-centric orientation + descriptors for keypoint lists in scan order.
+//
+// The per-keypoint kernel above fetches ~2 KB around every keypoint with row-strided loads (31 rows
+// of 36 bytes for the moments, 45 rows of 48 bytes for the sampling window); what bounds it is the
+// number of cache lines those loads touch, not arithmetic.  Here a workgroup owns one 256 x 64 image
+// tile, loads it ONCE with its 22 / 24-pixel halo into LDS by coalesced row loads (zero outside the
+// image, which is what both the clipped moments and the out-of-image samples need), and serves all
+// keypoints whose centre lies in the tile from there.  The keypoints of a 64-row band are one
+// contiguous range of the frame's list (scan order), known from the row prefix; every tile of the
+// band scans that range for its columns.
+// ---------------------------------------------------------------------------------------------
+constexpr int DT_W = 240, DT_H = 64;                 // 1920 and 3840 are whole numbers of tiles
+constexpr int DT_MX = 32, DT_MY = 22;                // left / top margin: >= 21, multiple of 16 / even
+constexpr int DT_PITCH = DT_W + 2 * DT_MX;           // 304 bytes per LDS row
+constexpr int DT_PITCH_DW = DT_PITCH / 4;            // 76
+constexpr int DT_PITCH_Q = DT_PITCH / 16;            // 19 16-byte units
+constexpr int DT_ROWS = DT_H + 2 * DT_MY - 1;        // 107: rows -22 .. +84 of the band
+constexpr int DT_UNITS = DT_ROWS * DT_PITCH_Q;       // 2033
+constexpr int DT_STEPS = (DT_UNITS + 255) / 256;     // tile load steps of 256 units (one per thread)
+constexpr int DT_SEG = 256;                          // list entries scanned per pass (one per thread)
+constexpr int DT_LCAP = 384;                         // keypoints gathered before they are processed
+constexpr int DT_BATCH = 128;                        // keypoints per moments / trigonometry / descriptor round
+static_assert(DT_W % 16 == 0 && DT_MX % 16 == 0 && DT_MY % 2 == 0 && DT_MX >= 22 && DT_MY >= 21, "halo, even origin, aligned units");
+static_assert(DT_ROWS * DT_PITCH < 65536, "LDS byte index fits 16 bits");
+static_assert(256 == 13 * DT_PITCH_Q + 9, "tile walk: 256 units on = 13 rows and 9 units");
+
+struct DescribeTileLds {
+    uint32_t tile32[DT_UNITS * 4];
+    // the last load step writes whole waves: up to 256 * DT_STEPS - DT_UNITS units past the tile, into cs,
+    // which holds nothing yet at that time
+    double2 cs[DT_BATCH];                            // moments, then (cos, sin)
+    uint32_t lst_xy[DT_LCAP];                        // (row in tile << 16) | column in tile
+    int32_t lst_idx[DT_LCAP];                        // keypoint index in the frame; later its descriptor slot
+    int lst_count;
+};
+static_assert((256 * DT_STEPS - DT_UNITS) * 16 <= (int)sizeof(double2) * DT_BATCH, "load overrun stays inside cs");
+static_assert(sizeof(DescribeTileLds) <= 40960, "four workgroups per CU");
+
+__global__ __launch_bounds__(256, 4) void describe_tile_kernel(
+    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
+    const int2* __restrict__ rowoff, float* __restrict__ kp7, uint8_t* __restrict__ desc,
+    int32_t* __restrict__ valid_idx, int ntc, int nbands)
+{
+    __shared__ __attribute__((aligned(16))) DescribeTileLds L;
+    uint32_t* const tile32 = L.tile32;
+    uint32_t* const lst_xy = L.lst_xy;
+    int32_t* const lst_idx = L.lst_idx;
+    double2* const cs = L.cs;
+
+    const uint32_t item = xcd_contiguous_item();
+    const int tc = (int)(item % (uint32_t)ntc);
+    const uint32_t rest = item / (uint32_t)ntc;
+    const int band = (int)(rest % (uint32_t)nbands);
+    const int f = (int)(rest / (uint32_t)nbands);
+    int n = counts[2 * f];
+    n = n < cap ? n : cap;
+    const int2* ro = rowoff + (size_t)f * H;
+    int k0 = ro[band * DT_H].x;
+    int k1 = (band + 1) * DT_H < H ? ro[(band + 1) * DT_H].x : n;
+    k0 = k0 < n ? k0 : n;
+    k1 = k1 < n ? k1 : n;
+    if (k0 >= k1) return;                            // no keypoints in this band (uniform)
+
+    const int t = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int X0 = tc * DT_W, tx0 = X0 - DT_MX, ty0 = band * DT_H - DT_MY;
+    const uint8_t* img = gray + (size_t)f * H * W;
+    const size_t kf = (size_t)f * cap;
+    const uint8_t* const pb = reinterpret_cast<const uint8_t*>(tile32);
+
+    // first pass of the list scan: in flight together with the tile
+    int2 pnext = make_int2(-1, -1);
+    if (k0 + t < k1) pnext = kpxy[kf + k0 + t];
+
+    // ---- the tile: rows ty0 .. ty0 + 106, columns tx0 .. tx0 + 303, straight into LDS in 16-byte units.
+    // Bounds-checked buffer loads return zero past either end of the frame (rows above and below the image);
+    // units left or right of the image get an offset that is out of range on purpose (W is a multiple of
+    // 16 and so is tx0: a unit is inside or outside as a whole). ----
+#ifndef DT_NO_TILE
+    {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, H * W, 0x00020000);
+        int row = t / DT_PITCH_Q;
+        int gx = tx0 + 16 * (t - row * DT_PITCH_Q);
+        int off = (ty0 + row) * W + gx;
+#pragma unroll
+        for (int k = 0; k < DT_STEPS; ++k) {
+            const bool ok = gx >= 0 && gx < W && (k + 1 < DT_STEPS || t + 256 * k < DT_UNITS);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(tile32 + 4 * (256 * k + 64 * wave)), 16,
+                ok ? (uint32_t)off : 0x80000000u, 0, 0, 0);
+            const bool wrap = gx + 16 * 9 >= tx0 + DT_PITCH;
+            gx += wrap ? 16 * 9 - DT_PITCH : 16 * 9;
+            off += wrap ? 14 * W + 16 * 9 - DT_PITCH : 13 * W + 16 * 9;
+        }
+    }
+#endif
+    if (t == 0) L.lst_count = 0;
+
+    // this lane's four test pairs, as doubles.  (A rotation table in LDS, as the per-keypoint kernel keeps,
+    // would cost 16 KB of LDS reads per keypoint: with the image tile in LDS as well, that is the limit.)
+    double dpx1[4], dpy1[4], dpx2[4], dpy2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
+        dpx1[r] = (double)(int8_t)(q & 255u);
+        dpy1[r] = (double)(int8_t)((q >> 8) & 255u);
+        dpx2[r] = (double)(int8_t)((q >> 16) & 255u);
+        dpy2[r] = (double)(int8_t)(q >> 24);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s0 = k0; s0 < k1; s0 += DT_SEG) {
+        // ---- gather: entries of the band's range whose column falls into this tile ----
+        const int2 p = pnext;
+        pnext = make_int2(-1, -1);
+        if (s0 + DT_SEG + t < k1) pnext = kpxy[kf + s0 + DT_SEG + t];
+        if (p.x >= X0 && p.x < X0 + DT_W) {
+            const int pos = atomicAdd(&L.lst_count, 1);
+            lst_xy[pos] = ((uint32_t)(p.y - ty0) << 16) | (uint32_t)(p.x - tx0);
+            lst_idx[pos] = s0 + t;
+        }
+        __syncthreads();
+        const int cnt = L.lst_count;
+        const bool last = s0 + DT_SEG >= k1;
+        if (!(cnt > DT_LCAP - DT_SEG || last)) continue;     // (uniform) room for another pass
+        if (cnt > 0) {
+            for (int bb = 0; bb < cnt; bb += DT_BATCH) {
+                const int nb = (cnt - bb) < DT_BATCH ? (cnt - bb) : DT_BATCH;
+                // ---- moments: 16 keypoints per step over the workgroup, 16 lanes each ----
+#ifndef DT_NO_MOM
+                {
+                    const int g = lane >> 4, q = lane & 15;
+                    for (int e0 = 0; e0 < nb; e0 += 16) {
+                        const int e = e0 + 4 * wave + g;
+                        const bool valid = e < nb;
+                        const uint32_t pxy = lst_xy[bb + (valid ? e : 0)];
+                        const int lx = (int)(pxy & 0xFFFFu), ly = (int)(pxy >> 16);
+                        const int r = (lx - 15) & 3;
+                        const int xa = (lx - 15) - r;
+                        const int rs = q < 15 ? q / 3 : 0, ch = q < 15 ? q % 3 : 0;
+                        const bool lane_on = valid && q < 15;
+                        uint32_t mk[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        if (ch == 0) mk[0] = 0xFFFFFFFFu << (8 * r);
+                        if (ch == 2) {
+                            mk[1] = r == 0 ? 0x00FFFFFFu : 0xFFFFFFFFu;
+                            mk[2] = r < 2 ? 0u : (r == 2 ? 0x000000FFu : 0x0000FFFFu);
+                        }
+                        if (!lane_on) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; }
+                        uint32_t w[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) w[j] = (uint32_t)(4 * (3 * ch + j) - r + 1) * 0x01010101u + 0x03020100u;
+                        if (ch == 0) w[0] = 0x04030201u << (8 * r);
+                        const uint32_t* src = tile32 + (ly - 15 + rs) * DT_PITCH_DW + (xa >> 2) + 3 * ch;
+                        uint32_t t00 = 0, t10 = 0;
+                        int t01 = 0;
+#pragma unroll
+                        for (int it = 0; it < 7; ++it) {
+                            uint32_t rsum = 0;
+                            const bool rowin = it < 6 || rs == 0;       // rows 30 .. 34: only row 30 is in the patch
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const uint32_t pm = (rowin ? src[5 * it * DT_PITCH_DW + j] : 0u) & mk[j];
+                                rsum = __builtin_amdgcn_sad_u8(pm, 0u, rsum);
+                                t10 = __builtin_amdgcn_udot4(pm, w[j], t10, false);
+                            }
+                            t00 += rsum;
+                            t01 += __mul24(rs + 5 * it - 15, (int)rsum);
+                        }
+                        int s00 = (int)t00, s10 = (int)t10 - 16 * (int)t00, s01 = t01;
+                        s00 = dpp_add<0x111, 0xf>(s00); s10 = dpp_add<0x111, 0xf>(s10); s01 = dpp_add<0x111, 0xf>(s01);
+                        s00 = dpp_add<0x112, 0xf>(s00); s10 = dpp_add<0x112, 0xf>(s10); s01 = dpp_add<0x112, 0xf>(s01);
+                        s00 = dpp_add<0x114, 0xf>(s00); s10 = dpp_add<0x114, 0xf>(s10); s01 = dpp_add<0x114, 0xf>(s01);
+                        s00 = dpp_add<0x118, 0xf>(s00); s10 = dpp_add<0x118, 0xf>(s10); s01 = dpp_add<0x118, 0xf>(s01);
+                        if (valid && q == 15) {
+                            int* m = reinterpret_cast<int*>(&cs[e]);
+                            m[0] = s00; m[1] = s10; m[2] = s01;
+                        }
+                    }
+                }
+#endif
+                __syncthreads();
+                // ---- one keypoint per thread: angle, keypoint row, cos / sin ----
+                if (t < nb) {
+                    const int* m = reinterpret_cast<const int*>(&cs[t]);
+                    const float angle = angle_from_moments(m[0], m[1], m[2]);
+                    const uint32_t pxy = lst_xy[bb + t];
+                    const int i = lst_idx[bb + t];
+                    float* row = kp7 + (kf + i) * 7;
+                    row[0] = (float)((int)(pxy & 0xFFFFu) + tx0); row[1] = (float)((int)(pxy >> 16) + ty0);
+                    row[2] = 7.0f; row[3] = angle; row[4] = 0.0f; row[5] = 0.0f; row[6] = -1.0f;
+                    const int slot = kpslot[kf + i];
+                    if (slot >= 0 && valid_idx) valid_idx[kf + slot] = i;
+                    lst_idx[bb + t] = slot;
+                    if (slot >= 0) {
+                        const double rad = (double)angle * (ORB_PI / 180.0);
+                        double2 v;
+#ifdef DT_NO_TRIG
+                        v.x = 1.0 - rad * 0.001;
+                        v.y = rad * 0.01;
+#else
+                        v.x = cos(rad);
+                        v.y = sin(rad);
+#endif
+                        cs[t] = v;
+                    }
+                }
+                __syncthreads();
+                // ---- descriptors: the waves take the keypoints of the batch in turn ----
+#ifndef DT_NO_DESC
+                for (int e = wave; e < nb; e += 4) {
+                    const int slot = __builtin_amdgcn_readfirstlane(lst_idx[bb + e]);
+                    if (slot < 0) continue;
+                    const uint32_t pxy = lst_xy[bb + e];
+                    const double2 csv = cs[e];
+                    const double cj = csv.x, sn = csv.y;
+                    float cx = (float)((int)(pxy & 0xFFFFu) + tx0), cy = (float)((int)(pxy >> 16) + ty0);
+                    float mx = RND_MAGIC - (float)tx0, my = RND_MAGIC - (float)ty0;
+                    uint32_t pitch = DT_PITCH;
+                    asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my), "+v"(pitch));
+                    uint32_t i1[4], i2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x1r = (float)(dpx1[r] * cj - dpy1[r] * sn);
+                        const float y1r = (float)(dpx1[r] * sn + dpy1[r] * cj);
+                        const float x2r = (float)(dpx2[r] * cj - dpy2[r] * sn);
+                        const float y2r = (float)(dpx2[r] * sn + dpy2[r] * cj);
+                        const uint32_t ax = __float_as_uint((cx + x1r) + mx);
+                        const uint32_t ay = __float_as_uint((cy + y1r) + my);
+                        const uint32_t bx = __float_as_uint((cx + x2r) + mx);
+                        const uint32_t by = __float_as_uint((cy + y2r) + my);
+                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i1[r]) : "v"(ay), "v"(pitch), "v"(ax));
+                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i2[r]) : "v"(by), "v"(pitch), "v"(bx));
+                    }
+                    int v1[4], v2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v1[r] = pb[i1[r]]; v2[r] = pb[i2[r]]; }
+                    unsigned long long bal[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bal[r] = __ballot(v1[r] < v2[r]);
+                    if (lane < 4) {
+                        const unsigned long long wd = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
+                        reinterpret_cast<unsigned long long*>(desc + (kf + slot) * 32)[lane] = wd;
+                    }
+                }
+#endif
+                __syncthreads();
+            }
+        }
+        if (t == 0) L.lst_count = 0;
+        __syncthreads();
+    }
+}
+
+void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts,
+                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
+{
+    const int ntc = (fs.W + DT_W - 1) / DT_W, nbands = (fs.H + DT_H - 1) / DT_H;
+    hipLaunchKernelGGL(describe_tile_kernel, dim3((unsigned)((size_t)ntc * nbands * fs.frames)), dim3(256), 0, s,
+                       fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, rowoff, kp7, desc, valid_idx, ntc, nbands);
+}
+
 void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
                             const int32_t* counts, int cap, const float* angle_in, float* kp7,
                             float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s)

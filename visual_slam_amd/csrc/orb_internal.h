@@ -46,6 +46,12 @@ void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t*
                             const int32_t* counts, int cap, const float* angle_in, float* kp7,
                             float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s);
 
+// The same results for whole frames whose keypoint lists are in scan order (as launch_emit leaves them),
+// computed tile by tile from LDS: rowoff [frames][H] as written by launch_rowscan.  Needs rows of whole
+// aligned 16-byte units (W % 16 == 0, 16-byte-aligned frames); kp7 and desc must not be NULL.
+void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts,
+                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, hipStream_t s);
+
 struct Knn2Args {
     const uint8_t* qdesc;     // query descriptor base
     const uint8_t* tdesc;     // train descriptor base
