@@ -328,9 +328,11 @@ def main():
     traffic_file = tfiles[-1] if tfiles else ""          # the latest round's measurement
     if args.preset == "1080p" and F == 1000 and os.path.exists(traffic_file):
         pmc = json.load(open(traffic_file))
+        # whole aligned 16-byte rows (the presets): the frame-batch path describes tile by tile
+        describe_kernel = "describe_tile_kernel" if W % 16 == 0 else "orient_describe_kernel"
         for name, key in (("fast_mask", "fast_mask_kernel"),
                           ("rowscan", "rowscan_kernel"), ("emit", "emit_kernel"),
-                          ("orient_describe", "orient_describe_kernel"),
+                          ("orient_describe", describe_kernel),
                           ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
             if name in rooflines and key in pmc:
                 rooflines[name]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
@@ -341,8 +343,9 @@ def main():
                                            "r*_pmc_instruction_mix_1080p_1000frames.json")))
     if args.preset == "1080p" and F == 1000 and ifiles:
         mix = json.load(open(ifiles[-1]))
+        describe_kernel = "describe_tile_kernel" if W % 16 == 0 else "orient_describe_kernel"
         for name, key in (("fast_mask", "fast_mask_kernel"), ("emit", "emit_kernel"),
-                          ("orient_describe", "orient_describe_kernel"),
+                          ("orient_describe", describe_kernel),
                           ("knn2", "knn2_kernel" if args.matcher == "valu" else "knn2_mfma_kernel")):
             if name in rooflines and key in mix and "SQ_INSTS_VALU" in mix[key]:
                 insts = mix[key]["SQ_INSTS_VALU"]

@@ -625,3 +625,35 @@ def test_reserve_presizes_the_work_buffers(eng):
         e2.ctx.reserve(0, H, W, 512)
     with pytest.raises(_lib.OrbAmdError):
         e2.ctx.reserve(3, H, W, 0)
+
+
+@pytest.mark.parametrize("scene,H,W,frames", [("sparse", 1080, 1920, 3), ("textured", 1080, 1920, 2),
+                                              ("sparse", 50, 48, 3), ("textured", 64, 240, 2),
+                                              ("textured", 65, 256, 2), ("noise", 130, 496, 2)])
+def test_tile_and_per_keypoint_describe_kernels_agree(eng8k, scene, H, W, frames):
+    """The frame-batch path describes keypoints tile by tile when the frames are made of whole aligned
+    16-byte units, and keypoint by keypoint otherwise.  The same frames at a 16-byte-aligned address and
+    at an address 4 bytes further on take one path each; every output must be identical (bit patterns of
+    the angles included)."""
+    import torch
+    eng = eng8k
+    if scene == "sparse":
+        g = eng.synth_frames(frames, H, W, first_frame=11, cell=12)
+    elif scene == "textured":
+        g = eng.synth_textured_frames(frames, H, W, first_frame=5)
+    else:
+        g = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (frames, H, W), dtype=np.uint8)).to(eng.device)
+    assert g.data_ptr() % 16 == 0 and (H * W) % 16 == 0
+    raw = torch.empty(frames * H * W + 16, dtype=torch.uint8, device=eng.device)
+    shifted = raw[4:4 + frames * H * W].view(frames, H, W)
+    shifted.copy_(g)
+    assert shifted.data_ptr() % 16 == 4
+    a = eng.extract_batch(g)
+    b = eng.extract_batch(shifted)
+    torch.cuda.synchronize()
+    assert torch.equal(a.counts, b.counts) and int(a.counts[:, 1].min()) > 0
+    for i in range(frames):
+        n, nv = (min(int(v), a.cap) for v in a.counts[i])
+        assert torch.equal(a.kp7[i, :n].view(torch.int32), b.kp7[i, :n].view(torch.int32))
+        assert torch.equal(a.desc[i, :nv], b.desc[i, :nv])
+        assert torch.equal(a.valid_idx[i, :nv], b.valid_idx[i, :nv])

@@ -1574,7 +1574,6 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
     // Bounds-checked buffer loads return zero past either end of the frame (rows above and below the image);
     // units left or right of the image get an offset that is out of range on purpose (W is a multiple of
     // 16 and so is tx0: a unit is inside or outside as a whole). ----
-#ifndef DT_NO_TILE
     {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, H * W, 0x00020000);
         int row = t / DT_PITCH_Q;
@@ -1591,7 +1590,6 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
             off += wrap ? 14 * W + 16 * 9 - DT_PITCH : 13 * W + 16 * 9;
         }
     }
-#endif
     if (t == 0) L.lst_count = 0;
 
     // this lane's four test pairs, as doubles.  (A rotation table in LDS, as the per-keypoint kernel keeps,
@@ -1626,11 +1624,10 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
             for (int bb = 0; bb < cnt; bb += DT_BATCH) {
                 const int nb = (cnt - bb) < DT_BATCH ? (cnt - bb) : DT_BATCH;
                 // ---- moments: 16 keypoints per step over the workgroup, 16 lanes each ----
-#ifndef DT_NO_MOM
                 {
                     const int g = lane >> 4, q = lane & 15;
-                    for (int e0 = 0; e0 < nb; e0 += 16) {
-                        const int e = e0 + 4 * wave + g;
+                    for (int e0 = 4 * wave; e0 < nb; e0 += 16) {      // a wave without keypoints left is done
+                        const int e = e0 + g;
                         const bool valid = e < nb;
                         const uint32_t pxy = lst_xy[bb + (valid ? e : 0)];
                         const int lx = (int)(pxy & 0xFFFFu), ly = (int)(pxy >> 16);
@@ -1647,9 +1644,10 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                         if (!lane_on) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; }
                         uint32_t w[3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) w[j] = (uint32_t)(4 * (3 * ch + j) - r + 1) * 0x01010101u + 0x03020100u;
+                        for (int j = 0; j < 3; ++j)       // the byte 4 (3 ch + j) - r + 1 in all four lanes, plus 0 1 2 3
+                            w[j] = __builtin_amdgcn_perm(0u, (uint32_t)(4 * (3 * ch + j) - r + 1), 0u) + 0x03020100u;
                         if (ch == 0) w[0] = 0x04030201u << (8 * r);
-                        const uint32_t* src = tile32 + (ly - 15 + rs) * DT_PITCH_DW + (xa >> 2) + 3 * ch;
+                        const uint32_t* src = tile32 + __mul24(ly - 15 + rs, DT_PITCH_DW) + (xa >> 2) + 3 * ch;
                         uint32_t t00 = 0, t10 = 0;
                         int t01 = 0;
 #pragma unroll
@@ -1676,7 +1674,6 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                         }
                     }
                 }
-#endif
                 __syncthreads();
                 // ---- one keypoint per thread: angle, keypoint row, cos / sin ----
                 if (t < nb) {
@@ -1693,19 +1690,13 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                     if (slot >= 0) {
                         const double rad = (double)angle * (ORB_PI / 180.0);
                         double2 v;
-#ifdef DT_NO_TRIG
-                        v.x = 1.0 - rad * 0.001;
-                        v.y = rad * 0.01;
-#else
                         v.x = cos(rad);
                         v.y = sin(rad);
-#endif
                         cs[t] = v;
                     }
                 }
                 __syncthreads();
                 // ---- descriptors: the waves take the keypoints of the batch in turn ----
-#ifndef DT_NO_DESC
                 for (int e = wave; e < nb; e += 4) {
                     const int slot = __builtin_amdgcn_readfirstlane(lst_idx[bb + e]);
                     if (slot < 0) continue;
@@ -1713,9 +1704,8 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                     const double2 csv = cs[e];
                     const double cj = csv.x, sn = csv.y;
                     float cx = (float)((int)(pxy & 0xFFFFu) + tx0), cy = (float)((int)(pxy >> 16) + ty0);
-                    float mx = RND_MAGIC - (float)tx0, my = RND_MAGIC - (float)ty0;
-                    uint32_t pitch = DT_PITCH;
-                    asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my), "+v"(pitch));
+                    const float mx = RND_MAGIC - (float)tx0, my = RND_MAGIC - (float)ty0;
+                    const uint32_t pitch = DT_PITCH;
                     uint32_t i1[4], i2[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1727,8 +1717,8 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                         const uint32_t ay = __float_as_uint((cy + y1r) + my);
                         const uint32_t bx = __float_as_uint((cx + x2r) + mx);
                         const uint32_t by = __float_as_uint((cy + y2r) + my);
-                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i1[r]) : "v"(ay), "v"(pitch), "v"(ax));
-                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i2[r]) : "v"(by), "v"(pitch), "v"(bx));
+                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i1[r]) : "v"(ay), "s"(pitch), "v"(ax));
+                        asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i2[r]) : "v"(by), "s"(pitch), "v"(bx));
                     }
                     int v1[4], v2[4];
 #pragma unroll
@@ -1741,7 +1731,6 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                         reinterpret_cast<unsigned long long*>(desc + (kf + slot) * 32)[lane] = wd;
                     }
                 }
-#endif
                 __syncthreads();
             }
         }
