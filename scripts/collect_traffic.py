@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-WIDE_STREAMING = ("fast_mask_kernel",)   # kernels whose global reads are 16 B per lane, coalesced
+WIDE_STREAMING = ("fast_mask_kernel", "describe_tile_kernel")   # kernels whose global reads are 16 B per lane, coalesced
 
 
 def per_kernel(path, counter):
