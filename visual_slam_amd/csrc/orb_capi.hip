@@ -298,6 +298,26 @@ int run_knn2(orbamd_ctx* c, Knn2Args& a, void* scratch_mem = nullptr, size_t scr
     return ORBAMD_OK;
 }
 
+// Orientation + descriptors for the scan-ordered lists in c->kpxy / c->kpslot (as run_emit leaves them).
+// Frames made of whole aligned 16-byte units are described tile by tile from LDS, the others keypoint by
+// keypoint; the results are the same.
+int run_describe(orbamd_ctx* c, const FrameSet& fs, const int32_t* d_counts, int cap, float* d_kp7,
+                 uint8_t* d_desc, int32_t* d_valid_idx)
+{
+    static const bool per_keypoint = getenv("ORBAMD_DESCRIBE_PER_KEYPOINT") != nullptr;   // (for A/B timing)
+    const bool tiles = !per_keypoint && (fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0;
+    {
+        Timed t(c, ORBAMD_K_DESCRIBE);
+        if (tiles)
+            launch_describe_tiles(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap,
+                                  (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, c->stream);
+        else
+            launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
+                                   d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
+    }
+    return post_launch(c, tiles ? "describe_tile_kernel" : "orient_describe_kernel");
+}
+
 // Single-frame extract on a gray frame already in c->gray.
 int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
 {
@@ -314,13 +334,8 @@ int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
         CHK(ensure(c, c->desc, (size_t)n * 32));
         CHK(ensure(c, c->vidx, (size_t)n * sizeof(int32_t)));
         FrameSet fs{d_gray, 1, H, W};
-        {
-            Timed t(c, ORBAMD_K_DESCRIBE);
-            launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
-                                   (const int32_t*)c->counts.p, n, nullptr, (float*)c->kp7.p, nullptr,
-                                   (uint8_t*)c->desc.p, (int32_t*)c->vidx.p, c->stream);
-        }
-        CHK(post_launch(c, "orient_describe_kernel"));
+        CHK(run_describe(c, fs, (const int32_t*)c->counts.p, n, (float*)c->kp7.p, (uint8_t*)c->desc.p,
+                         (int32_t*)c->vidx.p));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->last_n = n;
@@ -782,18 +797,7 @@ int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, i
     CHK(run_detect_counts(c, d_gray, frames, H, W, d_counts));
     CHK(run_emit(c, d_gray, frames, H, W, cap, d_counts));
     FrameSet fs{d_gray, frames, H, W};
-    static const bool per_keypoint = getenv("ORBAMD_DESCRIBE_PER_KEYPOINT") != nullptr;
-    const bool tiles = !per_keypoint && (W & 15) == 0 && ((uintptr_t)d_gray & 15) == 0;
-    {
-        Timed t(c, ORBAMD_K_DESCRIBE);
-        if (tiles)
-            launch_describe_tiles(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap,
-                                  (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, c->stream);
-        else
-            launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
-                                   d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
-    }
-    return post_launch(c, tiles ? "describe_tile_kernel" : "orient_describe_kernel");
+    return run_describe(c, fs, d_counts, cap, d_kp7, d_desc, d_valid_idx);
 }
 
 int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int frames, int cap,
