@@ -1999,6 +1999,7 @@ __device__ __forceinline__ uint32_t knn2_decode_key(float f, int tiles, int row0
 }
 
 constexpr int KNN2_RUN_TILES = 256;   // 8192 rows: the index field of a float key must stay below 2.0
+constexpr int KNN2_GROUP = 4;         // train tiles staged per workgroup barrier
 
 // One wave's share of a workgroup: QT query tiles (32 queries each) -- tiles qtile_first,
 // qtile_first + 4, ... (the four waves of a workgroup take the query tiles of their block round-robin)
@@ -2058,86 +2059,101 @@ __device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32
         if (t < tfull_all) return load_u32_at(reinterpret_cast<const uint8_t*>(trows), off);
         return t * 32 + srow < nt ? load_u32_at(reinterpret_cast<const uint8_t*>(trows), off) : 0u;
     };
-    uint32_t next = 0u;
-    if (tbeg < tend) next = fetch(tbeg);
     int run_row0 = tbeg * 32, run_tiles = 0;
     v16f pend;                                    // accumulators whose top-2 selection is still due
 #pragma unroll
     for (int i = 0; i < 16; ++i) pend[i] = -INFINITY;
-    // One train tile: stage it, then (waves with queries) multiply and select.  c0 = accumulator start.
-    auto step = [&](int t, const v16f& c0) {
-        const int buf = (t - tbeg) & 1;
-        stage[buf][threadIdx.x] = fp4_of_bits(next);
-        __syncthreads();
-        if (t + 1 < tend) next = fetch(t + 1);
-        if (wave_has_queries) {
-            v8i a[4];
+    // One staged train tile (waves with queries): multiply and select.  c0 = accumulator start.
+    auto compute = [&](int t, const uint4* tile, const v16f& c0) {
+        v8i a[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 v = stage[buf][ks * 64 + lane];
-                a[ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
-            }
-            // Every chain of four matrix instructions is issued together with the top-2 selection of
-            // the accumulators produced BEFORE it (the previous query tile's; for the first chain the
-            // last query tile's of the previous train tile, carried across the barrier in `pend`), so
-            // the vector instructions never wait for a matrix result and always have matrix work to
-            // overlap with.
-            v16f prev = pend;
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 v = tile[ks * 64 + lane];
+            a[ks] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+        }
+        // Every chain of four matrix instructions is issued together with the top-2 selection of
+        // the accumulators produced BEFORE it (the previous query tile's; for the first chain the
+        // last query tile's of the previous train tile, carried over in `pend`), so the vector
+        // instructions never wait for a matrix result and always have matrix work to overlap with.
+        v16f prev = pend;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            const int pu = (u + QT - 1) % QT;             // the query tile `prev` belongs to
+            v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[pu], m2[pu], prev[i], prev[i + 1], pinf);
+            m1[pu] += 32.0f / 4096.0f;
+            m2[pu] += 32.0f / 4096.0f;
+            prev = acc;
+            // schedule: one matrix instruction, then a quarter of the vector work, four times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+        pend = prev;
+        ++run_tiles;
+        if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
+            // end of a key run: the last query tile's accumulators are still pending
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[QT - 1], m2[QT - 1], pend[i], pend[i + 1], pinf);
+            m1[QT - 1] += 32.0f / 4096.0f;
+            m2[QT - 1] += 32.0f / 4096.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pend[i] = -INFINITY;
 #pragma unroll
             for (int u = 0; u < QT; ++u) {
-                const int pu = (u + QT - 1) % QT;             // the query tile `prev` belongs to
-                v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[0], b[u][0], c0, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[pu], m2[pu], prev[i], prev[i + 1], pinf);
-                m1[pu] += 32.0f / 4096.0f;
-                m2[pu] += 32.0f / 4096.0f;
-                prev = acc;
-                // schedule: one matrix instruction, then a quarter of the vector work, four times
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                top2_insert(k1[u], k2[u], knn2_decode_key(m1[u], run_tiles, run_row0));
+                top2_insert(k1[u], k2[u], knn2_decode_key(m2[u], run_tiles, run_row0));
+                m1[u] = -INFINITY;
+                m2[u] = -INFINITY;
             }
-            pend = prev;
-            ++run_tiles;
-            if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
-                // end of a key run: the last query tile's accumulators are still pending
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[QT - 1], m2[QT - 1], pend[i], pend[i + 1], pinf);
-                m1[QT - 1] += 32.0f / 4096.0f;
-                m2[QT - 1] += 32.0f / 4096.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pend[i] = -INFINITY;
-#pragma unroll
-                for (int u = 0; u < QT; ++u) {
-                    top2_insert(k1[u], k2[u], knn2_decode_key(m1[u], run_tiles, run_row0));
-                    top2_insert(k1[u], k2[u], knn2_decode_key(m2[u], run_tiles, run_row0));
-                    m1[u] = -INFINITY;
-                    m2[u] = -INFINITY;
-                }
-                run_row0 += run_tiles * 32;
-                run_tiles = 0;
-            }
+            run_row0 += run_tiles * 32;
+            run_tiles = 0;
         }
     };
-    // whole tiles first; only the very last tile of the train set can be partial
+    // The train tiles are staged KNN2_GROUP at a time, so that the four waves meet at one barrier per
+    // group instead of one per tile; two groups of buffers alternate.  Whole tiles first; only the very
+    // last tile of the train set can be partial (rows past nt never win).
     int tfull = nt >> 5;
     tfull = tfull < tend ? tfull : tend;
-    int t = tbeg;
-    for (; t < tfull; ++t) step(t, cin);
-    if (t < tend) {                                   // rows past nt never win
-        v16f c0 = cin;
+    uint32_t next[KNN2_GROUP];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
-        step(t, c0);
+    for (int j = 0; j < KNN2_GROUP; ++j) next[j] = tbeg + j < tfull ? fetch(tbeg + j) : 0u;
+    int grp = 0, t = tbeg;
+    for (; t < tfull; t += KNN2_GROUP, grp ^= 1) {
+        uint4* const bufs = stage[grp * KNN2_GROUP];
+#pragma unroll
+        for (int j = 0; j < KNN2_GROUP; ++j) bufs[j * 256 + threadIdx.x] = fp4_of_bits(next[j]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KNN2_GROUP; ++j) next[j] = t + KNN2_GROUP + j < tfull ? fetch(t + KNN2_GROUP + j) : 0u;
+        if (wave_has_queries) {
+            int g = tfull - t;
+            g = g < KNN2_GROUP ? g : KNN2_GROUP;
+#pragma unroll 1
+            for (int j = 0; j < g; ++j) compute(t + j, bufs + j * 256, cin);
+        }
+    }
+    const int tlast = tbeg > tfull ? tbeg : tfull;    // (an empty range may lie past the last whole tile)
+    if (tlast < tend) {                               // the partial tile, alone behind a barrier of its own
+        uint4* const bufs = stage[grp * KNN2_GROUP];
+        bufs[threadIdx.x] = fp4_of_bits(fetch(tlast));
+        __syncthreads();
+        if (wave_has_queries) {
+            v16f c0 = cin;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (tlast * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = -INFINITY;
+            compute(tlast, bufs, c0);
+        }
     }
 
     if (!wave_has_queries) return;
@@ -2180,7 +2196,7 @@ __global__ __launch_bounds__(256, 3) void knn2_mfma_kernel(const uint8_t* __rest
                                                         int32_t* __restrict__ idx, int32_t* __restrict__ dist,
                                                         uint8_t* __restrict__ good)
 {
-    __shared__ uint4 stage[2][256];
+    __shared__ uint4 stage[2 * KNN2_GROUP][256];
 
     int pair, zsplit, qblk;
     {
