@@ -1818,6 +1818,13 @@ __device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[8], const uin
     return d;
 }
 
+// The same for two rows held as two uint4 each.
+__device__ __forceinline__ uint32_t hamming256_regs(const uint4& q0, const uint4& q1, const uint4& t0, const uint4& t1)
+{
+    return (uint32_t)(__popc(q0.x ^ t0.x) + __popc(q0.y ^ t0.y) + __popc(q0.z ^ t0.z) + __popc(q0.w ^ t0.w) +
+                      __popc(q1.x ^ t1.x) + __popc(q1.y ^ t1.y) + __popc(q1.z ^ t1.z) + __popc(q1.w ^ t1.w));
+}
+
 // QPL queries per lane (register tiling over the query axis: one train row fetched per QPL * 64
 // pairs), RPT train rows per trip (their scalar loads are issued together), BS threads per block.
 template <int QPL, int RPT, int BS, bool PARTIAL>
@@ -1988,6 +1995,23 @@ __device__ __forceinline__ void top2_insert2_f32(float& m1, float& m2, float a, 
     m2 = __builtin_amdgcn_fmed3f(s2, m2, pinf);
 }
 
+// The 16 keys a lane holds of one tile into its running pair.  The registers 4 j .. 4 j + 3 are four
+// consecutive train rows (8 j + 4 (lane / 32) + 0 .. 3 of the tile): only the best key of each such quad
+// enters the top-2 update, 14 instructions instead of 24.  The running pair is then exact except for one
+// thing: the rows that share a quad with the best row never competed for second place.  (Any other row's
+// quad-mates are beaten by that row, so they cannot be second without it being first.)  Those three rows
+// are compared once per query at the end, knn2_repair_quad.
+__device__ __forceinline__ void knn2_select_tile(float& m1, float& m2, const v16f& acc, float pinf)
+{
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        q[j] = __builtin_amdgcn_fmed3f(__builtin_fmaxf(__builtin_fmaxf(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]),
+                                       acc[4 * j + 3], pinf);     // v_max3_f32, then max as med3(x, y, +inf)
+    top2_insert2_f32(m1, m2, q[0], q[1], pinf);
+    top2_insert2_f32(m1, m2, q[2], q[3], pinf);
+}
+
 // Float key after `tiles` tiles of a run that started at train row row0 -> integer key.
 __device__ __forceinline__ uint32_t knn2_decode_key(float f, int tiles, int row0)
 {
@@ -2083,27 +2107,16 @@ __device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32
             acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[1], b[u][1], acc, 4, 4, 0, scale_one, 0, scale_one);
             acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[2], b[u][2], acc, 4, 4, 0, scale_one, 0, scale_one);
             acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[3], b[u][3], acc, 4, 4, 0, scale_one, 0, scale_one);
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[pu], m2[pu], prev[i], prev[i + 1], pinf);
+            knn2_select_tile(m1[pu], m2[pu], prev, pinf);
             m1[pu] += 32.0f / 4096.0f;
             m2[pu] += 32.0f / 4096.0f;
             prev = acc;
-            // schedule: one matrix instruction, then a quarter of the vector work, four times
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
         }
         pend = prev;
         ++run_tiles;
         if (run_tiles == KNN2_RUN_TILES || t + 1 == tend) {
             // end of a key run: the last query tile's accumulators are still pending
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) top2_insert2_f32(m1[QT - 1], m2[QT - 1], pend[i], pend[i + 1], pinf);
+            knn2_select_tile(m1[QT - 1], m2[QT - 1], pend, pinf);
             m1[QT - 1] += 32.0f / 4096.0f;
             m2[QT - 1] += 32.0f / 4096.0f;
 #pragma unroll
@@ -2157,12 +2170,44 @@ __device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32
     }
 
     if (!wave_has_queries) return;
+    // Lanes l and l + 32 hold disjoint train rows of the same query: merge them.
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         const uint32_t p1 = (uint32_t)__shfl_xor((int)k1[u], 32);
         const uint32_t p2 = (uint32_t)__shfl_xor((int)k2[u], 32);
         top2_insert(k1[u], k2[u], p1);
         top2_insert(k1[u], k2[u], p2);
+    }
+    // The rows that shared a quad with the best row (see knn2_select_tile) now compete for second place:
+    // lane l takes best ^ 1 and best ^ 3, lane l + 32 best ^ 2, by XOR and popcount.  All loads of the
+    // wave's query tiles go out together.
+    uint4 rq[QT][2], ra4[QT][2], rb4[QT][2];
+    int ra[QT], rb[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
+        const bool have = k1[u] != KEY_NONE && qi < nq;
+        const int best = (int)(k1[u] & 0x3FFFFu);
+        ra[u] = have ? best ^ (h ? 2 : 1) : nt;
+        rb[u] = have && h == 0 ? best ^ 3 : nt;
+        const uint4* qp = reinterpret_cast<const uint4*>(qrows + (size_t)(have ? qi : 0) * 8);
+        const uint4* ap = reinterpret_cast<const uint4*>(trows + (size_t)(ra[u] < nt ? ra[u] : 0) * 8);
+        const uint4* bp = reinterpret_cast<const uint4*>(trows + (size_t)(rb[u] < nt ? rb[u] : 0) * 8);
+        rq[u][0] = qp[0]; rq[u][1] = qp[1];
+        ra4[u][0] = ap[0]; ra4[u][1] = ap[1];
+        rb4[u][0] = bp[0]; rb4[u][1] = bp[1];
+    }
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const uint32_t da = hamming256_regs(rq[u][0], rq[u][1], ra4[u][0], ra4[u][1]);
+        const uint32_t db = hamming256_regs(rq[u][0], rq[u][1], rb4[u][0], rb4[u][1]);
+        const uint32_t ka = ra[u] < nt ? (da << 18) | (uint32_t)ra[u] : KEY_NONE;
+        const uint32_t kb = rb[u] < nt ? (db << 18) | (uint32_t)rb[u] : KEY_NONE;
+        const uint32_t oa = (uint32_t)__shfl_xor((int)ka, 32), ob = (uint32_t)__shfl_xor((int)kb, 32);
+        top2_insert(k1[u], k2[u], ka);
+        top2_insert(k1[u], k2[u], kb);
+        top2_insert(k1[u], k2[u], oa);
+        top2_insert(k1[u], k2[u], ob);
         const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
         if (h == 0 && qi < nq) {
             if (PARTIAL) {
