@@ -1995,21 +1995,23 @@ __device__ __forceinline__ void top2_insert2_f32(float& m1, float& m2, float a, 
     m2 = __builtin_amdgcn_fmed3f(s2, m2, pinf);
 }
 
-// The 16 keys a lane holds of one tile into its running pair.  The registers 4 j .. 4 j + 3 are four
-// consecutive train rows (8 j + 4 (lane / 32) + 0 .. 3 of the tile): only the best key of each such quad
-// enters the top-2 update, 14 instructions instead of 24.  The running pair is then exact except for one
-// thing: the rows that share a quad with the best row never competed for second place.  (Any other row's
-// quad-mates are beaten by that row, so they cannot be second without it being first.)  Those three rows
-// are compared once per query at the end, knn2_repair_quad.
+// The 16 keys a lane holds of one tile into its running pair.  The registers 8 j .. 8 j + 7 are the train
+// rows 16 j + 4 (lane / 32) + {0 .. 3, 8 .. 11} of the tile: only the best key of each such group of eight
+// enters the top-2 update, 11 instructions instead of 24.  The running pair is then exact except for one
+// thing: the rows that share a group with the best row never competed for second place.  (Any other row's
+// group-mates are beaten by that row, so they cannot be second without it being first.)  Those seven rows
+// are compared once per query at the end of knn2_mfma_wave.
 __device__ __forceinline__ void knn2_select_tile(float& m1, float& m2, const v16f& acc, float pinf)
 {
-    float q[4];
+    float q[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        q[j] = __builtin_amdgcn_fmed3f(__builtin_fmaxf(__builtin_fmaxf(acc[4 * j], acc[4 * j + 1]), acc[4 * j + 2]),
-                                       acc[4 * j + 3], pinf);     // v_max3_f32, then max as med3(x, y, +inf)
+    for (int j = 0; j < 2; ++j) {
+        float r = __builtin_fmaxf(__builtin_fmaxf(acc[8 * j], acc[8 * j + 1]), acc[8 * j + 2]);      // v_max3_f32
+        r = __builtin_fmaxf(__builtin_fmaxf(r, acc[8 * j + 3]), acc[8 * j + 4]);
+        r = __builtin_fmaxf(__builtin_fmaxf(r, acc[8 * j + 5]), acc[8 * j + 6]);
+        q[j] = __builtin_amdgcn_fmed3f(r, acc[8 * j + 7], pinf);                                     // max as med3(x, y, +inf)
+    }
     top2_insert2_f32(m1, m2, q[0], q[1], pinf);
-    top2_insert2_f32(m1, m2, q[2], q[3], pinf);
 }
 
 // Float key after `tiles` tiles of a run that started at train row row0 -> integer key.
@@ -2178,43 +2180,58 @@ __device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32
         top2_insert(k1[u], k2[u], p1);
         top2_insert(k1[u], k2[u], p2);
     }
-    // The rows that shared a quad with the best row (see knn2_select_tile) now compete for second place:
-    // lane l takes best ^ 1 and best ^ 3, lane l + 32 best ^ 2, by XOR and popcount.  All loads of the
-    // wave's query tiles go out together.
-    uint4 rq[QT][2], ra4[QT][2], rb4[QT][2];
-    int ra[QT], rb[QT];
+    // The rows that shared a group of eight with the best row (see knn2_select_tile) now compete for second
+    // place, by XOR and popcount: the group is best's tile + (best & 20) + {0 .. 3, 8 .. 11}; counting on from
+    // best's own place in it, lane l takes the 1st, 3rd, 5th and 7th, lane l + 32 the 2nd, 4th and 6th.  The
+    // loads of two query tiles go out together.
+    constexpr int UB = QT >= 2 ? 2 : 1;
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-        const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
-        const bool have = k1[u] != KEY_NONE && qi < nq;
-        const int best = (int)(k1[u] & 0x3FFFFu);
-        ra[u] = have ? best ^ (h ? 2 : 1) : nt;
-        rb[u] = have && h == 0 ? best ^ 3 : nt;
-        const uint4* qp = reinterpret_cast<const uint4*>(qrows + (size_t)(have ? qi : 0) * 8);
-        const uint4* ap = reinterpret_cast<const uint4*>(trows + (size_t)(ra[u] < nt ? ra[u] : 0) * 8);
-        const uint4* bp = reinterpret_cast<const uint4*>(trows + (size_t)(rb[u] < nt ? rb[u] : 0) * 8);
-        rq[u][0] = qp[0]; rq[u][1] = qp[1];
-        ra4[u][0] = ap[0]; ra4[u][1] = ap[1];
-        rb4[u][0] = bp[0]; rb4[u][1] = bp[1];
-    }
+    for (int u0 = 0; u0 < QT; u0 += UB) {
+        uint4 rq[UB][2], rt[UB][4][2];
+        int rr[UB][4];
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-        const uint32_t da = hamming256_regs(rq[u][0], rq[u][1], ra4[u][0], ra4[u][1]);
-        const uint32_t db = hamming256_regs(rq[u][0], rq[u][1], rb4[u][0], rb4[u][1]);
-        const uint32_t ka = ra[u] < nt ? (da << 18) | (uint32_t)ra[u] : KEY_NONE;
-        const uint32_t kb = rb[u] < nt ? (db << 18) | (uint32_t)rb[u] : KEY_NONE;
-        const uint32_t oa = (uint32_t)__shfl_xor((int)ka, 32), ob = (uint32_t)__shfl_xor((int)kb, 32);
-        top2_insert(k1[u], k2[u], ka);
-        top2_insert(k1[u], k2[u], kb);
-        top2_insert(k1[u], k2[u], oa);
-        top2_insert(k1[u], k2[u], ob);
-        const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
-        if (h == 0 && qi < nq) {
-            if (PARTIAL) {
-                const size_t o = (((size_t)pair * splits + zsplit) * cap + qi);
-                reinterpret_cast<uint2*>(partial)[o] = make_uint2(k1[u], k2[u]);
-            } else {
-                knn2_store(k1[u], k2[u], idx, dist, good, (size_t)pair * cap + qi);
+        for (int v = 0; v < UB; ++v) {
+            const int u = u0 + v;
+            if (u >= QT) break;
+            const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
+            const bool have = k1[u] != KEY_NONE && qi < nq;
+            const int best = (int)(k1[u] & 0x3FFFFu);
+            const int base = best & ~11, pos = ((best >> 1) & 4) | (best & 3);      // place 0 .. 7 within the group
+            const uint4* qp = reinterpret_cast<const uint4*>(qrows + (size_t)(have ? qi : 0) * 8);
+            rq[v][0] = qp[0]; rq[v][1] = qp[1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int place = (pos + 1 + 2 * k + h) & 7;
+                const int row = base + ((place & 4) << 1) + (place & 3);
+                rr[v][k] = have && place != pos && row < nt ? row : -1;
+                const uint4* tp = reinterpret_cast<const uint4*>(trows + (size_t)(rr[v][k] >= 0 ? rr[v][k] : 0) * 8);
+                rt[v][k][0] = tp[0]; rt[v][k][1] = tp[1];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < UB; ++v) {
+            const int u = u0 + v;
+            if (u >= QT) break;
+            uint32_t kk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t d = hamming256_regs(rq[v][0], rq[v][1], rt[v][k][0], rt[v][k][1]);
+                kk[k] = rr[v][k] >= 0 ? (d << 18) | (uint32_t)rr[v][k] : KEY_NONE;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)kk[k], 32);
+                top2_insert(k1[u], k2[u], kk[k]);
+                top2_insert(k1[u], k2[u], other);
+            }
+            const int qi = (qtile_first + 4 * u) * 32 + (lane & 31);
+            if (h == 0 && qi < nq) {
+                if (PARTIAL) {
+                    const size_t o = (((size_t)pair * splits + zsplit) * cap + qi);
+                    reinterpret_cast<uint2*>(partial)[o] = make_uint2(k1[u], k2[u]);
+                } else {
+                    knn2_store(k1[u], k2[u], idx, dist, good, (size_t)pair * cap + qi);
+                }
             }
         }
     }
