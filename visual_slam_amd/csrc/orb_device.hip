@@ -1948,9 +1948,10 @@ __global__ __launch_bounds__(BS) void knn2_kernel(const uint8_t* __restrict__ qd
 // registers of a lane (row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  Starting the
 // accumulator at -256 - row / 4096 makes each register -(2 * distance + row / 4096): a complete
 // (distance, train index) key as one exact float (10 integer bits + 12 fraction bits), larger =
-// better, so the running top-2 of a lane is one v_med3_f32 and one v_max_f32 per element and no
-// key has to be built.  After every tile the two running keys are raised by 32 / 4096, which
-// makes their index fields relative to the start of the next tile (negative for rows already
+// better, so no key has to be built: the 16 keys of a lane are reduced to the best of each group of
+// eight rows and those two enter the lane's running top-2 (knn2_select_tile).  After every tile the
+// two running keys are raised by 32 / 4096, which makes their index fields relative to the start of
+// the next tile (negative for rows already
 // seen); the fields stay inside the distance step of 2 for 8192 rows, after which (and at the
 // end) the keys are decoded into the integer (distance << 18) | index form and merged there.
 // Lanes l and l + 32 hold disjoint train rows of the same query and are merged at the end.
