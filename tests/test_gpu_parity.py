@@ -157,6 +157,29 @@ def test_knn2_low_entropy_ties(gctx, matcher):
     assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
 
 
+@pytest.mark.parametrize("nt", [40, 1000, 6000])
+def test_knn2_second_best_next_to_the_best(gctx, matcher, nt):
+    """The runner-up sits at a fixed small distance in rows from the winner: inside the same group of four
+    or eight train rows the matrix-core kernel keeps only one key of per tile, across a group boundary, and
+    in the next tile.  Every query is a train row, its runner-up a near-copy of that row."""
+    rng = np.random.default_rng(5 + nt)
+    for step in (1, 2, 3, 4, 8, 9, 11, 12, 16, 31, 32):
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        src = np.arange(0, nt - step, 2 * step + 1)
+        t[src + step] = t[src]
+        t[src + step, 5] ^= 0x10                       # runner-up at distance 1, `step` rows further on
+        q = t[src].copy()
+        idx, dist = gctx.knn2(q, t)
+        eidx, edist = oracle.c.knn2(q, t)
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist), step
+        assert np.array_equal(idx[:, 0], src) and np.array_equal(idx[:, 1], src + step)
+        # and the other way round: the near-copy first, the exact row after it
+        q2 = t[src + step].copy()
+        idx, dist = gctx.knn2(q2, t)
+        eidx, edist = oracle.c.knn2(q2, t)
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist), -step
+
+
 def test_knn2_extreme_distances(gctx, matcher):
     """Distances 0 and 256 (all bits equal / all bits different) and rows of all zeros / all ones."""
     rng = np.random.default_rng(77)
