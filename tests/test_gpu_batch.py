@@ -629,7 +629,8 @@ def test_reserve_presizes_the_work_buffers(eng):
 
 @pytest.mark.parametrize("scene,H,W,frames", [("sparse", 1080, 1920, 3), ("textured", 1080, 1920, 2),
                                               ("sparse", 50, 48, 3), ("textured", 64, 240, 2),
-                                              ("textured", 65, 256, 2), ("noise", 130, 496, 2)])
+                                              ("textured", 65, 256, 2), ("noise", 130, 496, 2),
+                                              ("noise", 64, 960, 3), ("noise", 200, 1920, 1)])
 def test_tile_and_per_keypoint_describe_kernels_agree(eng8k, scene, H, W, frames):
     """The frame-batch path describes keypoints tile by tile when the frames are made of whole aligned
     16-byte units, and keypoint by keypoint otherwise.  The same frames at a 16-byte-aligned address and

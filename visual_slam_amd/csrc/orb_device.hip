@@ -1499,13 +1499,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // Tile-centric orientation + descriptors for keypoint lists in scan order.
 //
 // The per-keypoint kernel above fetches ~2 KB around every keypoint with row-strided loads (31 rows
-// of 36 bytes for the moments, 45 rows of 48 bytes for the sampling window); what bounds it is the
-// number of cache lines those loads touch, not arithmetic.  Here a workgroup owns one 256 x 64 image
-// tile, loads it ONCE with its 22 / 24-pixel halo into LDS by coalesced row loads (zero outside the
+// of 36 bytes for the moments, 45 rows of 48 bytes for the sampling window) and stages a window per
+// keypoint.  Here a workgroup owns one 240 x 64 image tile, loads it ONCE with its halo (32 columns
+// left and right, 22 rows above, 21 below) into LDS by coalesced 16-byte loads (zero outside the
 // image, which is what both the clipped moments and the out-of-image samples need), and serves all
-// keypoints whose centre lies in the tile from there.  The keypoints of a 64-row band are one
-// contiguous range of the frame's list (scan order), known from the row prefix; every tile of the
-// band scans that range for its columns.
+// keypoints whose centre lies in the tile from there: what is left is vector arithmetic.  The
+// keypoints of a 64-row band are one contiguous range of the frame's list (scan order), known from
+// the row prefix; every tile of the band scans that range for its columns.
 // ---------------------------------------------------------------------------------------------
 constexpr int DT_W = 240, DT_H = 64;                 // 1920 and 3840 are whole numbers of tiles
 constexpr int DT_MX = 32, DT_MY = 22;                // left / top margin: >= 21, multiple of 16 / even
@@ -1618,6 +1618,7 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
         }
         __syncthreads();
         const int cnt = L.lst_count;
+        __syncthreads();                   // everybody has read the count before the next pass can add to it
         const bool last = s0 + DT_SEG >= k1;
         if (!(cnt > DT_LCAP - DT_SEG || last)) continue;     // (uniform) room for another pass
         if (cnt > 0) {
