@@ -46,10 +46,11 @@ VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0
 # Dense FP4 matrix-core peak (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4): 256 CUs x 4 SIMDs
 # x 4096 FLOP/clk x 2.4 GHz.
 MFMA_FP4_PEAK_TFLOPS = 10066.0
-# What the matcher's own inner pattern (four FP4 MFMAs + the 24-instruction top-2 selection of their 16
-# results per lane) sustains in a register-only loop at 4 waves per SIMD on MI355X: 88 ns per 32x32x256
-# unit and SIMD (visual_slam_amd/csrc/micro/mfma_top2_pattern.hip) = 1024 SIMDs x 524288 FLOP / 88 ns.
-MFMA_FP4_MEASURED_PATTERN_TFLOPS = 6100.0
+# What the matcher's four FP4 MFMAs per 32x32x256 unit sustain ALONE in a register-only loop at 4 waves per
+# SIMD on MI355X: 65.4 ns per unit and SIMD (visual_slam_amd/csrc/micro/mfma_top2_pattern.hip, column
+# "mfma"; 69.1 ns at the kernel's own 3 waves) = 1024 SIMDs x 524288 FLOP / 65.4 ns: the rate of the matrix
+# pipe itself at the clock the chip holds under this load, with no selection, staging or loop around it.
+MFMA_FP4_MEASURED_PATTERN_TFLOPS = 8210.0
 
 
 def parse_args():
