@@ -77,6 +77,13 @@ def parse_args():
                          "matched (20k x 20k Hamming top-2 per pair by default); pairs are independent, ranks share nothing")
     ap.add_argument("--sets", type=int, default=65, help="dense-match: descriptor sets per GPU (pairs = sets - 1)")
     ap.add_argument("--set-size", type=int, default=20000, help="dense-match: rows per descriptor set")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1.  nccl (= RCCL, one GPU per rank) is the product path; gloo "
+                         "stages the seam frame through host memory and lets several ranks share the visible GPUs "
+                         "(a rehearsal of the multi-rank path on a one-GPU machine, never a scaling figure)")
+    ap.add_argument("--dropin-calls", type=int, default=40,
+                    help="calls of the reference's own call shape (one BGR frame per call through build/orb_project) "
+                         "timed beside the headline (N = 1 only; 0 = skip)")
     ap.add_argument("--matcher", default="matrix", choices=["matrix", "valu"],
                     help="Hamming top-2 kernel family: matrix cores (default) or XOR/popcount on the vector ALUs")
     return ap.parse_args()
@@ -98,6 +105,41 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def init_ranks(args, local_rank, world):
+    """Select this rank's GPU and join the process group.  Returns the device index in use."""
+    import torch
+    import torch.distributed as dist
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())     # ranks share the visible GPUs
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+        if dist.get_world_size() != args.gpus:
+            sys.exit("bench: the process group has %d ranks but --gpus is %d" % (dist.get_world_size(), args.gpus))
+    return local_rank
+
+
+def max_over_ranks(args, value, world, op_min=False):
+    """MAX (or MIN) of a host scalar over the ranks."""
+    if world == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN if op_min else dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def git_blob_id(path):
+    """The id git gives this file's contents (sha1 of "blob <size>\\0" + bytes), computed without git."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def dense_match(args, rank, local_rank, world):
     """The dense matching stress case: `sets - 1` independent pairs of set_size x set_size BRIEF-256
     Hamming top-2 per rank and step, descriptor sets resident in HBM (i.i.d. bytes, 1 % duplicated rows so
@@ -107,9 +149,7 @@ def dense_match(args, rank, local_rank, world):
     from visual_slam_amd import _lib, synth
     from visual_slam_amd.engine import BatchFeatures, OrbEngine
 
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    local_rank = init_ranks(args, local_rank, world)
     S, N = args.sets, args.set_size
     eng = OrbEngine(local_rank, cap=N)
     eng.set_matcher(_lib.MATCHER_VALU if args.matcher == "valu" else _lib.MATCHER_MATRIX)
@@ -133,10 +173,7 @@ def dense_match(args, rank, local_rank, world):
         eng.match_consecutive(feat, out=matches)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(args, dt, world)
     eng.ctx.timing_enable(True)
     eng.ctx.timing_reset()
     for _ in range(max(1, args.profile_steps)):
@@ -189,7 +226,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
-    args.gpus = world
+    if world != args.gpus:
+        sys.exit("bench: started as %d rank(s) but --gpus is %d" % (world, args.gpus))
     if args.workload == "dense-match":
         return dense_match(args, rank, local_rank, world)
 
@@ -197,11 +235,9 @@ def main():
     import torch.distributed as dist
     from visual_slam_amd import synth
     from visual_slam_amd.engine import OrbEngine
-    from visual_slam_amd.scheduler import FrameRangeScheduler, partition_frames, unpack_boundary
+    from visual_slam_amd.scheduler import FrameRangeScheduler, partition_frames
 
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    local_rank = init_ranks(args, local_rank, world)
 
     P = synth.PRESETS[args.preset]
     H, W = P["H"], P["W"]
@@ -226,19 +262,13 @@ def main():
     sched = FrameRangeScheduler(eng, rank, world, with_keypoints=True)
 
     def step():
-        if args.chunks > 1:
+        if args.chunks > 1 and world == 1:
             # extraction of frame range k+1 overlaps the matching of range k (second stream)
             eng.extract_and_match(gray, feat, matches, chunks=args.chunks)
-            reqs, rbuf = sched.exchange(feat)
-        else:
-            eng.extract_batch(gray, out=feat)
-            reqs, rbuf = sched.exchange(feat)
-            eng.match_consecutive(feat, out=matches)
-        for r in reqs:
-            r.wait()
-        if rbuf is not None:
-            b = unpack_boundary(rbuf, cap, True)
-            eng.match_cross(feat, 0, b.desc, b.counts, out=seam)
+            return None
+        # N > 1: the last frame is extracted first and sent to the next rank while the rest of the range is
+        # extracted and matched; the previous rank's last frame arrives meanwhile and the seam pair is matched
+        return sched.process(gray, first_frame=first_frame, out=feat, matches=matches, seam=seam)
 
     def fence():
         torch.cuda.synchronize()
@@ -253,13 +283,42 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(args, time.perf_counter() - t0, world)
     ms_per_step = dt / args.steps * 1e3
     value = total_units * args.steps / dt
+
+    # ---- N > 1: every rank checks the seam it received against its own computation -------------------
+    # Rank r > 0 regenerates frame first_frame - 1 (the previous rank's last frame: all ranks cut one seeded
+    # scene), extracts it here, and compares on the device what arrived (counts, live descriptor rows, live
+    # keypoint rows) and the seam pair's top-2 + ratio flags with the locally computed ones.
+    seam_verified = None
+    seam_wire = None
+    if world > 1:
+        ok = 1.0
+        res = step()
+        torch.cuda.synchronize()
+        if rank > 0:
+            prev = eng.synth_frames(1, H, W, first_frame=first_frame - 1, cell=P["cell"], density=P["density"])
+            pf = eng.extract_batch(prev)
+            local = eng.match_cross(feat, 0, pf.desc, pf.counts)
+            torch.cuda.synchronize()
+            b = res.boundary
+            pn, pnd = (int(v) for v in pf.counts[0].tolist())
+            pnk, pnd = min(pn, cap), min(pnd, cap)
+            nq = min(int(feat.counts[0, 1]), cap)
+            good = (b is not None and b.counts[0].tolist() == pf.counts[0].tolist()
+                    and torch.equal(b.desc[0, :pnd], pf.desc[0, :pnd])
+                    and torch.equal(b.kp7[0, :pnk].view(torch.int32), pf.kp7[0, :pnk].view(torch.int32))
+                    and torch.equal(seam.idx[0, :nq], local.idx[0, :nq])
+                    and torch.equal(seam.dist[0, :nq], local.dist[0, :nq])
+                    and torch.equal(seam.good[0, :nq], local.good[0, :nq])
+                    and res.wire_bytes_received == 16 + 32 * pnd + 28 * pnk)
+            if not good:
+                ok = 0.0
+                print("bench: rank %d: the seam frame received from rank %d or its matches differ from the "
+                      "local computation" % (rank, rank - 1), file=sys.stderr)
+        seam_verified = max_over_ranks(args, ok, world, op_min=True) == 1.0
+        seam_wire = {"bytes_sent_rank0": res.wire_bytes_sent, "capacity_padded_bytes": 16 + cap * 60}
     # what the process group saw: one entry per rank (rank, local device index, device name)
     devices = [(rank, torch.cuda.current_device(), torch.cuda.get_device_name())]
     rccl_world = 1
@@ -268,6 +327,7 @@ def main():
         dist.all_gather_object(gathered, devices[0])
         devices = gathered
         rccl_world = dist.get_world_size()
+        assert rccl_world == args.gpus, "process group size differs from --gpus"
 
     # ---- per-kernel timing (HIP events on the launch stream), untimed for `value` ------------
     # One kernel at a time on one stream (whole batch per launch): a kernel's duration is only
@@ -327,8 +387,13 @@ def main():
     tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                            "r*_pmc_traffic_1080p_1000frames.json")))
     traffic_file = tfiles[-1] if tfiles else ""          # the latest round's measurement
+    counter_sources = {}
     if args.preset == "1080p" and F == 1000 and os.path.exists(traffic_file):
         pmc = json.load(open(traffic_file))
+        counter_sources["traffic"] = {"file": "profiles/" + os.path.basename(traffic_file),
+                                      "git_blob": git_blob_id(traffic_file),
+                                      "note": "rocprofv3 PMC passes of this workload on an earlier run of the same "
+                                              "kernels, not measured in this run"}
         # whole aligned 16-byte rows (the presets): the frame-batch path describes tile by tile
         describe_kernel = "describe_tile_kernel" if W % 16 == 0 else "orient_describe_kernel"
         for name, key in (("fast_mask", "fast_mask_kernel"),
@@ -344,6 +409,10 @@ def main():
                                            "r*_pmc_instruction_mix_1080p_1000frames.json")))
     if args.preset == "1080p" and F == 1000 and ifiles:
         mix = json.load(open(ifiles[-1]))
+        counter_sources["instruction_mix"] = {"file": "profiles/" + os.path.basename(ifiles[-1]),
+                                              "git_blob": git_blob_id(ifiles[-1]),
+                                              "note": "SQ_INSTS_VALU pass of this workload on an earlier run of the "
+                                                      "same kernels, not measured in this run"}
         describe_kernel = "describe_tile_kernel" if W % 16 == 0 else "orient_describe_kernel"
         for name, key in (("fast_mask", "fast_mask_kernel"), ("emit", "emit_kernel"),
                           ("orient_describe", describe_kernel),
@@ -356,6 +425,16 @@ def main():
                     "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
                     "frac": rate / 1e9 / VALU_ISSUE_PEAK_GINST,
                     "per_keypoint": insts / max(1.0, float(n.sum())) if name == "orient_describe" else None}
+    # Orientation + descriptors: the reference's double -> float -> cvRound chain costs a fixed number of vector
+    # instructions per test pair, so the kernel's real bound is vector-instruction issue; the HBM figure is kept
+    # beside it.
+    od = rooflines.get("orient_describe")
+    if od is not None and "valu_issue" in od:
+        vi = od.pop("valu_issue")
+        hbm = {k: od[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        od.update({"bound": "valu_issue", "achieved": vi["achieved"], "peak": vi["peak"], "unit": vi["unit"],
+                   "frac": vi["frac"], "wave_insts_per_launch": vi["wave_insts_per_launch"],
+                   "wave_insts_per_keypoint": vi["per_keypoint"], "hbm": hbm})
     dominant = max(rooflines, key=lambda k: rooflines[k]["avg_ms"]) if rooflines else None
 
     # ---- the same steps with the XOR/popcount matcher on the vector ALUs (reported beside `value`) --
@@ -454,6 +533,57 @@ def main():
                              "(visual_slam_amd/synth.py synth_textured_frame)"}
         del teng, tgray, tfeat, tmatches
 
+    # ---- the reference's own call shape: one BGR frame per call through build/orb_project ---------------
+    # orb.extract(frame) + knn_match2(d, d_prev) + ratio_filter, host arrays in and out every time
+    # (reference views.py:273, :162-171).  PCIe and launch latency bound this, not the kernels; it is
+    # reported beside `value`, never as `value`.
+    dropin = None
+    if rank == 0 and world == 1 and args.dropin_calls > 1:
+        import importlib
+        orbmod = importlib.import_module("build.orb_project")
+        K = min(args.dropin_calls, F - 1)
+        host_gray = gray[:K + 1].cpu().numpy()
+        # B = G = R = v converts back to exactly v: (v * 32768 + 16384) >> 15
+        bgr = np.ascontiguousarray(np.repeat(host_gray[..., None], 3, axis=3))
+        _, d_prev = orbmod.extract(bgr[0])
+        for _ in range(2):
+            kp, d = orbmod.extract(bgr[1])
+            orbmod.ratio_filter(*orbmod.knn_match2(d, d_prev))
+        orbmod.profile(True)
+        t_ext, t_knn, t_rat = [], [], []
+        for i in range(1, K + 1):
+            t0 = time.perf_counter()
+            kp, d = orbmod.extract(bgr[i])
+            t1 = time.perf_counter()
+            idx, dst = orbmod.knn_match2(d, d_prev)
+            t2 = time.perf_counter()
+            gq, g2, g1 = orbmod.ratio_filter(idx, dst)
+            t3 = time.perf_counter()
+            t_ext.append(t1 - t0), t_knn.append(t2 - t1), t_rat.append(t3 - t2)
+            d_prev = d
+        prof = orbmod.profile_read()
+        orbmod.profile(False)
+        bkp, bdesc, _ = feat.frame(K)
+        bidx, bdst, bgood = matches.pair(K - 1, len(bdesc))
+        same = bool(np.array_equal(kp.view(np.uint32), bkp.view(np.uint32)) and np.array_equal(d, bdesc)
+                    and np.array_equal(idx, bidx) and np.array_equal(dst, bdst)
+                    and np.array_equal(gq, np.nonzero(bgood)[0]))
+        med = lambda v: float(np.median(v)) * 1e6
+        total = [a + b + c for a, b, c in zip(t_ext, t_knn, t_rat)]
+        kernels_us = {k: v[0] / K * 1e3 for k, v in prof["kernel_ms"].items()}
+        in_bytes = 3 * H * W + 2 * 32 * len(d)
+        out_bytes = 28 * len(kp) + 32 * len(d) + 16 * len(d)
+        dropin = {"median_us_per_call": med(total), "frames_per_s": 1e6 / med(total),
+                  "extract_us": med(t_ext), "knn_match2_us": med(t_knn), "ratio_filter_us": med(t_rat),
+                  "host_us_per_call": {k: v / K for k, v in prof["host_us"].items()},
+                  "kernel_us_per_call": sum(kernels_us.values()), "kernels_us": kernels_us, "calls": K,
+                  "bytes_in_per_call": in_bytes, "bytes_out_per_call": out_bytes,
+                  "pcie_floor_us": (in_bytes + out_bytes) / 55e9 * 1e6,
+                  "matches_batch_path": same,
+                  "call": "orb_project.extract(bgr [%d,%d,3] uint8, pageable) + knn_match2(d, d_prev) + ratio_filter, "
+                          "results as fresh NumPy arrays (reference views.py:273, :162-171)" % (H, W)}
+        del bgr, host_gray
+
     # ---- CPU baseline + result check on a bounded sample (rank 0, N = 1) ------------------------
     cpu = None
     check = None
@@ -513,10 +643,19 @@ def main():
                                                          else "%d frames per GPU" % F, int(round(n.mean()))),
                        "frames_per_gpu": F, "total_frames": total_units, "keypoints_per_frame": float(n.mean()),
                        "descriptors_per_frame": float(nv.mean()), "capacity_per_frame": cap,
-                       "matcher": args.matcher, "pipelined_frame_ranges": args.chunks,
-                       "parallelism": "contiguous frame ranges, %d rank(s), RCCL send/recv of the seam frame"
-                                      % world},
-            "rccl_world_size": rccl_world,
+                       "matcher": args.matcher,
+                       "matcher_departure": ("the task's wording says 'no MFMA' for matching; the default matcher runs "
+                                             "Hamming distance as an exact +-1 FP4 dot product on the matrix cores, the "
+                                             "XOR/popcount family is `--matcher valu` and is priced in `roofline_int_valu`")
+                       if args.matcher == "matrix" else None,
+                       "pipelined_frame_ranges": args.chunks, "backend": args.backend if world > 1 else None,
+                       "parallelism": "contiguous frame ranges, %d rank(s), %s of the seam frame's live rows"
+                                      % (world, "RCCL send/recv" if args.backend == "nccl" else
+                                         "gloo send/recv through host memory (rehearsal, ranks share GPUs)")},
+            "rccl_world_size": rccl_world if args.backend == "nccl" else None,
+            "world_size": rccl_world,
+            "seam_verified": seam_verified,
+            "seam_wire": seam_wire,
             "rank_devices": [list(d) for d in devices],
             "roofline": rooflines.get(dominant),
             "roofline_kernel": dominant,
@@ -524,7 +663,13 @@ def main():
                                  "whole-batch launches, one kernel at a time (what --chunks 1 runs); the timed "
                                  "steps pipeline %d frame ranges on two streams" % args.chunks,
             "rooflines": rooflines,
+            "counter_sources": counter_sources,
+            # the bound the task names for matching: XOR + popcount on the integer vector ALUs
+            "roofline_int_valu": (dict(valu_alt["knn2_roofline"], kernel="knn2_kernel (--matcher valu)",
+                                       frames_per_s=valu_alt["value"]) if valu_alt and "knn2_roofline" in valu_alt
+                                  else (rooflines.get("knn2") if args.matcher == "valu" else None)),
             "valu_matcher": valu_alt,
+            "dropin_call": dropin,
             "textured_scene": textured,
             "cpu_baseline": cpu,
             "gpu_matches_cpu_on_sample": check,
@@ -535,6 +680,10 @@ def main():
         dist.destroy_process_group()
     if check is False or (textured is not None and textured["gpu_matches_cpu_on_sample"] is False):
         sys.exit("bench: GPU results differ from the CPU restatement on the sample")
+    if seam_verified is False:
+        sys.exit("bench: a rank received a seam frame that differs from its own computation")
+    if dropin is not None and dropin.get("matches_batch_path") is False:
+        sys.exit("bench: the single-frame call path and the batch path disagree")
 
 
 if __name__ == "__main__":

@@ -117,6 +117,21 @@ int orbamd_ctx_timing_reset(orbamd_ctx* ctx);
 int orbamd_ctx_timing_read(orbamd_ctx* ctx, double ms_out[ORBAMD_K_COUNT], long launches_out[ORBAMD_K_COUNT]);
 const char* orbamd_kernel_name(int kind);
 
+/* Where the HOST's wall time goes inside the single-frame, host-pointer calls (orbamd_extract_*,
+ * orbamd_fetch, orbamd_knn2), accumulated in microseconds while timing is enabled and cleared by
+ * orbamd_ctx_timing_reset():
+ *   H2D      copying the caller's arrays towards the device (staging into pinned memory + enqueueing the DMA)
+ *   ENQUEUE  sizing work buffers and launching kernels
+ *   WAIT     blocked until the device has finished
+ *   D2H      bringing results back (enqueueing the DMA + copying from pinned memory into the caller's arrays)
+ * No counterpart in the reference (its only timing is time.perf_counter around extract, views.py:269-279). */
+#define ORBAMD_HT_H2D       0
+#define ORBAMD_HT_ENQUEUE   1
+#define ORBAMD_HT_WAIT      2
+#define ORBAMD_HT_D2H       3
+#define ORBAMD_HT_COUNT     4
+int orbamd_ctx_host_timing_read(orbamd_ctx* ctx, double us_out[ORBAMD_HT_COUNT]);
+
 /* ---- single frame, host pointers (the drop-in path) -------------------------------------- */
 
 /* cv::cvtColor(frame, gray, COLOR_BGR2GRAY) for 8-bit input (reference

@@ -11,13 +11,18 @@ class OracleEngine:
     def __init__(self, cap=512):
         self.cap = cap
 
-    def extract_batch(self, gray):
+    def alloc_features(self, frames, cap=None):
+        cap = cap or self.cap
+        return BatchFeatures(kp7=torch.zeros((frames, cap, 7), dtype=torch.float32),
+                             desc=torch.zeros((frames, cap, 32), dtype=torch.uint8),
+                             valid_idx=torch.zeros((frames, cap), dtype=torch.int32),
+                             counts=torch.zeros((frames, 2), dtype=torch.int32), cap=cap)
+
+    def extract_batch(self, gray, out=None):
         frames = gray.shape[0]
-        cap = self.cap
-        kp7 = torch.zeros((frames, cap, 7), dtype=torch.float32)
-        desc = torch.zeros((frames, cap, 32), dtype=torch.uint8)
-        vidx = torch.zeros((frames, cap), dtype=torch.int32)
-        counts = torch.zeros((frames, 2), dtype=torch.int32)
+        out = out if out is not None else self.alloc_features(frames)
+        cap = out.cap
+        kp7, desc, vidx, counts = out.kp7, out.desc, out.valid_idx, out.counts
         for f in range(frames):
             kp, d, v = oracle.c.extract_gray(gray[f].numpy())
             n, nv = min(len(kp), cap), int((v < cap).sum())
@@ -26,7 +31,7 @@ class OracleEngine:
             vidx[f, :nv] = torch.from_numpy(v[:nv])
             # (n found, descriptor rows stored): the library's convention, also when n > cap
             counts[f, 0], counts[f, 1] = len(kp), int((v < cap).sum())
-        return BatchFeatures(kp7=kp7, desc=desc, valid_idx=vidx, counts=counts, cap=cap)
+        return out
 
     def _match(self, q, t):
         idx, dist = oracle.c.knn2(q, t)
@@ -35,9 +40,9 @@ class OracleEngine:
             good[oracle.c.ratio_filter(idx, dist)[0]] = 1
         return idx, dist, good
 
-    def _pack(self, results):
+    def _pack(self, results, out=None):
         cap = self.cap
-        m = BatchMatches(idx=torch.full((max(len(results), 1), cap, 2), -7, dtype=torch.int32),
+        m = out if out is not None else BatchMatches(idx=torch.full((max(len(results), 1), cap, 2), -7, dtype=torch.int32),
                          dist=torch.full((max(len(results), 1), cap, 2), -7, dtype=torch.int32),
                          good=torch.zeros((max(len(results), 1), cap), dtype=torch.uint8), cap=cap)
         for p, (idx, dist, good) in enumerate(results):
@@ -51,12 +56,12 @@ class OracleEngine:
         nv = min(int(counts[f, 1]), cap)
         return feat_desc[f, :nv].numpy()
 
-    def match_consecutive(self, feat):
+    def match_consecutive(self, feat, out=None):
         res = [self._match(self._desc(feat.desc, feat.counts, f, feat.cap), self._desc(feat.desc, feat.counts, f - 1, feat.cap))
                for f in range(1, feat.frames)]
-        return self._pack(res)
+        return self._pack(res, out)
 
-    def match_cross(self, feat, qframe, t_desc, t_counts, tframe=0):
+    def match_cross(self, feat, qframe, t_desc, t_counts, tframe=0, out=None):
         q = self._desc(feat.desc, feat.counts, qframe, feat.cap)
         t = self._desc(t_desc, t_counts, tframe, feat.cap)
-        return self._pack([self._match(q, t)])
+        return self._pack([self._match(q, t)], out)

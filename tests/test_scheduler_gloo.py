@@ -78,7 +78,8 @@ def _worker(rank, world, port, outdir, total=TOTAL):
             np.savez(os.path.join(outdir, "rank%d.npz" % rank), first=s, empty=1)
             dist.barrier()
             return
-        out = {"first": s, "counts": res.features.counts.numpy(),
+        out = {"first": s, "counts": res.features.counts.numpy(), "sent": res.wire_bytes_sent,
+               "received": res.wire_bytes_received,
                "idx": res.matches.idx.numpy(), "dist": res.matches.dist.numpy(), "good": res.matches.good.numpy()}
         if res.boundary_matches is not None:
             out.update(b_idx=res.boundary_matches.idx.numpy(), b_dist=res.boundary_matches.dist.numpy(),
@@ -121,8 +122,12 @@ def test_two_ranks_reproduce_the_single_process_matches(tmp_path):
             n_prev = len(ex[s - 1][0])
             assert np.array_equal(z["b_kp7"][0, :n_prev].view(np.uint32), ex[s - 1][0].view(np.uint32))
             seen_pairs.add(s)
+            # only the live rows travelled: 16-byte header + nd descriptors + n keypoint rows
+            assert int(z["received"]) == 16 + 32 * len(ex[s - 1][1]) + 28 * n_prev
         else:
-            assert "b_idx" not in z.files
+            assert "b_idx" not in z.files and int(z["received"]) == 0
+        if rank + 1 < world:
+            assert int(z["sent"]) == 16 + 32 * len(ex[e - 1][1]) + 28 * len(ex[e - 1][0])
     assert seen_pairs == set(range(1, TOTAL))          # every consecutive pair exactly once
 
 

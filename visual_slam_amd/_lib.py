@@ -43,6 +43,7 @@ SIGNATURES = {
     "orbamd_ctx_timing_reset": (_int, [_c_ctx]),
     "orbamd_ctx_timing_read": (_int, [_c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
     "orbamd_kernel_name": (ctypes.c_char_p, [_int]),
+    "orbamd_ctx_host_timing_read": (_int, [_c_ctx, ctypes.POINTER(ctypes.c_double)]),
     "orbamd_bgr2gray": (_int, [_c_ctx, _vp, _int, _int, _vp]),
     "orbamd_detect": (_int, [_c_ctx, _vp, _int, _int, _vp, _int, _intp]),
     "orbamd_orient": (_int, [_c_ctx, _vp, _int, _int, _vp, _int, _vp]),
@@ -189,6 +190,12 @@ class Context:
         n = (ctypes.c_long * K_COUNT)()
         self._chk(lib().orbamd_ctx_timing_read(self._h, ms, n), "timing_read")
         return {lib().orbamd_kernel_name(k).decode(): (ms[k], n[k]) for k in range(K_COUNT)}
+
+    def host_timing_read(self):
+        """-> {"h2d", "enqueue", "wait", "d2h"}: host microseconds inside the single-frame calls since the reset."""
+        us = (ctypes.c_double * 4)()
+        self._chk(lib().orbamd_ctx_host_timing_read(self._h, us), "host_timing_read")
+        return dict(zip(("h2d", "enqueue", "wait", "d2h"), (float(v) for v in us)))
 
     # -- single frame, host arrays ----------------------------------------------------------------
     @staticmethod

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -34,6 +35,11 @@ struct TimedLaunch {
     hipEvent_t a, b;
 };
 
+struct PinnedBuf {
+    uint8_t* p = nullptr;
+    size_t bytes = 0;
+};
+
 }  // namespace
 
 struct orbamd_ctx {
@@ -54,6 +60,15 @@ struct orbamd_ctx {
     // state of the last single-frame extract
     bool have_extract = false;
     int last_n = 0, last_nv = 0;
+    // Single-frame calls launch at a capacity instead of reading the keypoint count back first; the
+    // capacity grows when a frame exceeds it.  The first `spec_n` keypoint rows / `spec_nv` descriptor rows of
+    // the last extract were copied to pinned host memory speculatively, ahead of the call's one wait.
+    int single_cap = 16384;
+    int guess_rows = 8192;
+    int spec_n = 0, spec_nv = 0;
+    PinnedBuf in_stage, out_kp, out_desc, out_vidx, mt_stage;
+    bool stage_h2d = true;
+    double host_us[ORBAMD_HT_COUNT] = {0};
 
     // per-kernel timing
     bool timing = false;
@@ -97,6 +112,59 @@ int ensure(orbamd_ctx* c, DevBuf& b, size_t bytes)
     size_t want = bytes + bytes / 4;  // head room against repeated regrowth
     HIPCHK(c, hipMalloc(&b.p, want));
     b.bytes = want;
+    return ORBAMD_OK;
+}
+
+int ensure_pinned(orbamd_ctx* c, PinnedBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 64;
+    if (b.bytes >= bytes) return ORBAMD_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipHostFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    HIPCHK(c, hipHostMalloc((void**)&b.p, want, hipHostMallocDefault));
+    b.bytes = want;
+    return ORBAMD_OK;
+}
+
+// Host wall time of a region, added to one of the ORBAMD_HT_* shares while timing is on.
+struct HostPhase {
+    orbamd_ctx* c;
+    int kind;
+    std::chrono::steady_clock::time_point t0;
+    HostPhase(orbamd_ctx* c_, int kind_) : c(c_), kind(kind_)
+    {
+        if (c->timing) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostPhase()
+    {
+        if (c->timing)
+            c->host_us[kind] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+// Host -> device for a caller's (pageable) array.  Staged: copied piece by piece into pinned memory owned by
+// the context, each piece's DMA in flight while the next is being copied, so that nothing waits for the
+// device.  The pinned buffer is reused by the next call, which is why every host-pointer entry point ends
+// with a wait for the stream.
+int upload(orbamd_ctx* c, void* dst, const void* src, size_t bytes, PinnedBuf& stage)
+{
+    HostPhase hp(c, ORBAMD_HT_H2D);
+    if (!c->stage_h2d) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return ORBAMD_OK;
+    }
+    CHK(ensure_pinned(c, stage, bytes));
+    const size_t piece = 1u << 19;
+    for (size_t o = 0; o < bytes; o += piece) {
+        const size_t nb = bytes - o < piece ? bytes - o : piece;
+        memcpy(stage.p + o, (const uint8_t*)src + o, nb);
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + o, stage.p + o, nb, hipMemcpyHostToDevice, c->stream));
+    }
     return ORBAMD_OK;
 }
 
@@ -221,6 +289,7 @@ int run_emit(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int
 int read_counts(orbamd_ctx* c, const int32_t* d_counts, int nints)
 {
     HIPCHK(c, hipMemcpyAsync(c->h_counts, d_counts, sizeof(int32_t) * nints, hipMemcpyDeviceToHost, c->stream));
+    HostPhase hp(c, ORBAMD_HT_WAIT);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ORBAMD_OK;
 }
@@ -318,26 +387,55 @@ int run_describe(orbamd_ctx* c, const FrameSet& fs, const int32_t* d_counts, int
     return post_launch(c, tiles ? "describe_tile_kernel" : "orient_describe_kernel");
 }
 
-// Single-frame extract on a gray frame already in c->gray.
+// Single-frame extract on a gray frame already in (or on its way into) c->gray.  Everything is launched
+// at the context's single-frame capacity, so the keypoint count is not needed on the host before the
+// last kernel; the counts and (speculatively, sized by the previous frame) the result rows travel to
+// pinned host memory behind the kernels, and the call waits for the device once.
 int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
 {
     c->have_extract = false;
     const uint8_t* d_gray = (const uint8_t*)c->gray.p;
-    CHK(ensure(c, c->counts, 16));
-    CHK(run_detect_counts(c, d_gray, 1, H, W, (int32_t*)c->counts.p));
-    CHK(read_counts(c, (const int32_t*)c->counts.p, 2));
-    const int n = c->h_counts[0], nv = c->h_counts[1];
-    if (n > ORBAMD_MAX_CAP) return ORBAMD_E_CAPACITY;
-    if (n > 0) {
-        CHK(run_emit(c, d_gray, 1, H, W, n, (int32_t*)c->counts.p));
-        CHK(ensure(c, c->kp7, (size_t)n * 7 * sizeof(float)));
-        CHK(ensure(c, c->desc, (size_t)n * 32));
-        CHK(ensure(c, c->vidx, (size_t)n * sizeof(int32_t)));
-        FrameSet fs{d_gray, 1, H, W};
-        CHK(run_describe(c, fs, (const int32_t*)c->counts.p, n, (float*)c->kp7.p, (uint8_t*)c->desc.p,
-                         (int32_t*)c->vidx.p));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    int n = 0, nv = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int cap = c->single_cap;
+        {
+            HostPhase hp(c, ORBAMD_HT_ENQUEUE);
+            CHK(ensure(c, c->counts, 16));
+            CHK(ensure(c, c->kp7, (size_t)cap * 7 * sizeof(float)));
+            CHK(ensure(c, c->desc, (size_t)cap * 32));
+            CHK(ensure(c, c->vidx, (size_t)cap * sizeof(int32_t)));
+            CHK(run_detect_counts(c, d_gray, 1, H, W, (int32_t*)c->counts.p));
+            CHK(run_emit(c, d_gray, 1, H, W, cap, (int32_t*)c->counts.p));
+            FrameSet fs{d_gray, 1, H, W};
+            CHK(run_describe(c, fs, (const int32_t*)c->counts.p, cap, (float*)c->kp7.p, (uint8_t*)c->desc.p,
+                             (int32_t*)c->vidx.p));
+        }
+        const int g = c->guess_rows < cap ? c->guess_rows : cap;
+        {
+            HostPhase hp(c, ORBAMD_HT_D2H);
+            CHK(ensure_pinned(c, c->out_kp, (size_t)g * 7 * sizeof(float)));
+            CHK(ensure_pinned(c, c->out_desc, (size_t)g * 32));
+            CHK(ensure_pinned(c, c->out_vidx, (size_t)g * sizeof(int32_t)));
+            HIPCHK(c, hipMemcpyAsync(c->h_counts, c->counts.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->out_kp.p, c->kp7.p, (size_t)g * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->out_desc.p, c->desc.p, (size_t)g * 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->out_vidx.p, c->vidx.p, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        }
+        {
+            HostPhase hp(c, ORBAMD_HT_WAIT);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        n = c->h_counts[0];
+        nv = c->h_counts[1];
+        if (n > ORBAMD_MAX_CAP) return ORBAMD_E_CAPACITY;
+        c->spec_n = g;
+        c->spec_nv = g;
+        if (n <= cap) break;
+        // more corners than the capacity: grow it and run the frame again (the second pass always fits)
+        c->single_cap = n + n / 4 < ORBAMD_MAX_CAP ? n + n / 4 : ORBAMD_MAX_CAP;
+        c->guess_rows = c->single_cap;
     }
+    c->guess_rows = n + n / 8 + 64;
     c->last_n = n;
     c->last_nv = nv;
     c->have_extract = true;
@@ -398,6 +496,8 @@ int orbamd_ctx_create(int device, orbamd_ctx** out)
     }
     if (const char* e = getenv("ORBAMD_MATCHER"))
         if (strcmp(e, "valu") == 0) c->matcher = ORBAMD_MATCHER_VALU;
+    if (const char* e = getenv("ORBAMD_STAGE_COPIES"))      // (0: hand the caller's pageable arrays to HIP as they are)
+        c->stage_h2d = atoi(e) != 0;
     *out = c;
     return ORBAMD_OK;
 }
@@ -432,6 +532,9 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    PinnedBuf* pins[] = {&c->in_stage, &c->out_kp, &c->out_desc, &c->out_vidx, &c->mt_stage};
+    for (PinnedBuf* b : pins)
+        if (b->p) (void)hipHostFree(b->p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ORBAMD_OK;
@@ -501,6 +604,15 @@ int orbamd_ctx_timing_reset(orbamd_ctx* c)
     CHK(enter(c));
     CHK(drain_timing(c));
     for (int k = 0; k < ORBAMD_K_COUNT; ++k) { c->ms[k] = 0; c->launches[k] = 0; }
+    for (int k = 0; k < ORBAMD_HT_COUNT; ++k) c->host_us[k] = 0;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_host_timing_read(orbamd_ctx* c, double us_out[ORBAMD_HT_COUNT])
+{
+    CHK(enter(c));
+    if (!us_out) return ORBAMD_E_BADARG;
+    for (int k = 0; k < ORBAMD_HT_COUNT; ++k) us_out[k] = c->host_us[k];
     return ORBAMD_OK;
 }
 
@@ -642,7 +754,7 @@ int orbamd_extract_gray(orbamd_ctx* c, const uint8_t* gray, int H, int W, int* n
     CHK(check_image(H, W));
     const size_t npix = (size_t)H * W;
     CHK(ensure(c, c->gray, npix));
-    HIPCHK(c, hipMemcpyAsync(c->gray.p, gray, npix, hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->gray.p, gray, npix, c->in_stage));
     return extract_resident(c, H, W, n_out, nv_out);
 }
 
@@ -654,7 +766,7 @@ int orbamd_extract_bgr(orbamd_ctx* c, const uint8_t* bgr, int H, int W, int* n_o
     const size_t npix = (size_t)H * W;
     CHK(ensure(c, c->bgr, npix * 3));
     CHK(ensure(c, c->gray, npix));
-    HIPCHK(c, hipMemcpyAsync(c->bgr.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+    CHK(upload(c, c->bgr.p, bgr, npix * 3, c->in_stage));
     {
         Timed t(c, ORBAMD_K_BGR2GRAY);
         launch_bgr2gray((const uint8_t*)c->bgr.p, (uint8_t*)c->gray.p, (long)npix, c->stream);
@@ -668,14 +780,29 @@ int orbamd_fetch(orbamd_ctx* c, float* kp7_out, uint8_t* desc_out, int32_t* vali
     CHK(enter(c));
     if (!c->have_extract) return ORBAMD_E_STATE;
     const int n = c->last_n, nv = c->last_nv;
-    if (n > 0 && kp7_out)
-        HIPCHK(c, hipMemcpyAsync(kp7_out, c->kp7.p, (size_t)n * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (nv > 0 && desc_out)
-        HIPCHK(c, hipMemcpyAsync(desc_out, c->desc.p, (size_t)nv * 32, hipMemcpyDeviceToHost, c->stream));
-    if (nv > 0 && valid_idx_out)
-        HIPCHK(c, hipMemcpyAsync(valid_idx_out, c->vidx.p, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                 c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HostPhase hp(c, ORBAMD_HT_D2H);
+    // rows the extract call already brought to pinned host memory are copied from there; a frame that
+    // outgrew the guess is fetched from the device
+    bool wait = false;
+    if (n > 0 && kp7_out) {
+        if (n <= c->spec_n) memcpy(kp7_out, c->out_kp.p, (size_t)n * 7 * sizeof(float));
+        else {
+            HIPCHK(c, hipMemcpyAsync(kp7_out, c->kp7.p, (size_t)n * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            wait = true;
+        }
+    }
+    if (nv > 0 && nv <= c->spec_nv) {
+        if (desc_out) memcpy(desc_out, c->out_desc.p, (size_t)nv * 32);
+        if (valid_idx_out) memcpy(valid_idx_out, c->out_vidx.p, (size_t)nv * sizeof(int32_t));
+    } else if (nv > 0) {
+        if (desc_out)
+            HIPCHK(c, hipMemcpyAsync(desc_out, c->desc.p, (size_t)nv * 32, hipMemcpyDeviceToHost, c->stream));
+        if (valid_idx_out)
+            HIPCHK(c, hipMemcpyAsync(valid_idx_out, c->vidx.p, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                     c->stream));
+        wait = true;
+    }
+    if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
     return ORBAMD_OK;
 }
 
@@ -690,8 +817,23 @@ int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     CHK(ensure(c, c->t, (size_t)nt * 32));
     CHK(ensure(c, c->idx, (size_t)nq * 2 * sizeof(int32_t)));
     CHK(ensure(c, c->dist, (size_t)nq * 2 * sizeof(int32_t)));
-    HIPCHK(c, hipMemcpyAsync(c->q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-    if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    {
+        // both descriptor sets through one pinned staging buffer (query rows first)
+        HostPhase hp(c, ORBAMD_HT_H2D);
+        if (c->stage_h2d) {
+            CHK(ensure_pinned(c, c->mt_stage, (size_t)(nq + nt) * 32));
+            memcpy(c->mt_stage.p, q, (size_t)nq * 32);
+            HIPCHK(c, hipMemcpyAsync(c->q.p, c->mt_stage.p, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+            if (nt > 0) {
+                memcpy(c->mt_stage.p + (size_t)nq * 32, t, (size_t)nt * 32);
+                HIPCHK(c, hipMemcpyAsync(c->t.p, c->mt_stage.p + (size_t)nq * 32, (size_t)nt * 32,
+                                         hipMemcpyHostToDevice, c->stream));
+            }
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+            if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+        }
+    }
     Knn2Args a{};
     a.qdesc = (const uint8_t*)c->q.p;
     a.tdesc = (const uint8_t*)c->t.p;
@@ -701,9 +843,32 @@ int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     a.nt_fixed = nt;
     a.idx = (int32_t*)c->idx.p;
     a.dist = (int32_t*)c->dist.p;
-    CHK(run_knn2(c, a));
-    HIPCHK(c, hipMemcpyAsync(idx_out, c->idx.p, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dist_out, c->dist.p, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    {
+        HostPhase hp(c, ORBAMD_HT_ENQUEUE);
+        CHK(run_knn2(c, a));
+    }
+    const size_t ob = (size_t)nq * 2 * sizeof(int32_t);
+    if (c->stage_h2d) {
+        // results to pinned memory behind the kernel, one wait, then into the caller's arrays
+        CHK(ensure_pinned(c, c->out_kp, 2 * ob));
+        {
+            HostPhase hp(c, ORBAMD_HT_D2H);
+            HIPCHK(c, hipMemcpyAsync(c->out_kp.p, c->idx.p, ob, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->out_kp.p + ob, c->dist.p, ob, hipMemcpyDeviceToHost, c->stream));
+        }
+        {
+            HostPhase hp(c, ORBAMD_HT_WAIT);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        HostPhase hp(c, ORBAMD_HT_D2H);
+        memcpy(idx_out, c->out_kp.p, ob);
+        memcpy(dist_out, c->out_kp.p + ob, ob);
+        c->spec_n = c->spec_nv = 0;      // the staging buffer no longer holds the last extract's rows
+        return ORBAMD_OK;
+    }
+    HostPhase hp(c, ORBAMD_HT_D2H);
+    HIPCHK(c, hipMemcpyAsync(idx_out, c->idx.p, ob, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist_out, c->dist.p, ob, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ORBAMD_OK;
 }

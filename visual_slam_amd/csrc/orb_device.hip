@@ -82,6 +82,16 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
     return s;
 }
 
+// Measurement knob: extra dynamic LDS per workgroup (bytes, from an environment variable) for one kernel,
+// which lowers how many of its workgroups fit a CU.  Never changes results.
+static unsigned lds_pad_from_env(const char* name, const void* kernel)
+{
+    const char* e = getenv(name);
+    const unsigned pad = e ? (unsigned)atoi(e) : 0u;
+    if (pad) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    return pad;
+}
+
 // Bits b of mask word w whose pixel x = 32w + b satisfies x - 16 >= 0 && x + 16 < W.
 __device__ __forceinline__ uint32_t desc_column_bits(int w, int W)
 {
@@ -1744,7 +1754,8 @@ void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* 
                            int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
 {
     const int ntc = (fs.W + DT_W - 1) / DT_W, nbands = (fs.H + DT_H - 1) / DT_H;
-    hipLaunchKernelGGL(describe_tile_kernel, dim3((unsigned)((size_t)ntc * nbands * fs.frames)), dim3(256), 0, s,
+    static const unsigned pad = lds_pad_from_env("ORBAMD_PAD_LDS_DESCRIBE", (const void*)describe_tile_kernel);
+    hipLaunchKernelGGL(describe_tile_kernel, dim3((unsigned)((size_t)ntc * nbands * fs.frames)), dim3(256), pad, s,
                        fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, rowoff, kp7, desc, valid_idx, ntc, nbands);
 }
 
@@ -2476,12 +2487,13 @@ void launch_knn2_mfma(const Knn2Args& a, hipStream_t s)
     const int nqmax = a.qcounts ? a.cap : a.nq_fixed;
     const int nbp = ((nqmax + 128 * QT - 1) / (128 * QT)) | 1;   // odd: see xcd_contiguous_item()
     dim3 grid((unsigned)((size_t)nbp * a.npairs * a.splits));
+    static const unsigned pad = lds_pad_from_env("ORBAMD_PAD_LDS_KNN2", (const void*)knn2_mfma_kernel<QT, false>);
     if (a.splits > 1)
         hipLaunchKernelGGL((knn2_mfma_kernel<QT, true>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
                            a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
     else
-        hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), 0, s, a.qdesc, a.tdesc,
+        hipLaunchKernelGGL((knn2_mfma_kernel<QT, false>), grid, dim3(256), pad, s, a.qdesc, a.tdesc,
                            a.qcounts, a.tcounts, a.pairs, a.qframe0, a.tframe0, a.nframes,
                            a.cap, a.nq_fixed, a.nt_fixed, a.splits, nbp, a.partial, a.idx, a.dist, a.good);
 }

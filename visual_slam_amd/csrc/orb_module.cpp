@@ -8,7 +8,7 @@
 // (src/main_interface.cpp:57-65, :89-98).
 //
 // Added entry points (the reference has no matcher in its module; it calls OpenCV from Python at
-// views.py:162): extract_gray, extract_indexed, knn_match2, ratio_filter.
+// views.py:162): extract_gray, extract_indexed, knn_match2, ratio_filter; profile / profile_read for measurement.
 //
 // This translation unit contains no image arithmetic; it only moves buffers through the C ABI.
 #include <pybind11/numpy.h>
@@ -191,6 +191,39 @@ py::tuple ratio_filter(const py::array_t<int32_t, py::array::c_style | py::array
     return py::make_tuple(head(gq), head(g2), head(g1));
 }
 
+// Per-kernel device time and the host's time shares inside the calls of this module (measurement aid; the
+// reference only wraps its call in time.perf_counter, views.py:269-279).
+void profile(bool enable)
+{
+    std::unique_lock<std::mutex> lock = lock_context();
+    orbamd_ctx* c = ctx();
+    check(orbamd_ctx_timing_enable(c, enable ? 1 : 0), "profile");
+    check(orbamd_ctx_timing_reset(c), "profile");
+}
+
+py::dict profile_read()
+{
+    std::unique_lock<std::mutex> lock = lock_context();
+    orbamd_ctx* c = ctx();
+    double ms[ORBAMD_K_COUNT];
+    long launches[ORBAMD_K_COUNT];
+    double us[ORBAMD_HT_COUNT];
+    check(orbamd_ctx_timing_read(c, ms, launches), "profile_read");
+    check(orbamd_ctx_host_timing_read(c, us), "profile_read");
+    py::dict kernels;
+    for (int k = 0; k < ORBAMD_K_COUNT; ++k)
+        if (launches[k]) kernels[orbamd_kernel_name(k)] = py::make_tuple(ms[k], launches[k]);
+    py::dict host;
+    host["h2d"] = us[ORBAMD_HT_H2D];
+    host["enqueue"] = us[ORBAMD_HT_ENQUEUE];
+    host["wait"] = us[ORBAMD_HT_WAIT];
+    host["d2h"] = us[ORBAMD_HT_D2H];
+    py::dict out;
+    out["kernel_ms"] = kernels;
+    out["host_us"] = host;
+    return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(orb_project, m)
@@ -206,4 +239,8 @@ PYBIND11_MODULE(orb_project, m)
           "Hamming 2-nearest neighbours of each row of d1 in d2: (idx int32 [N,2], dist int32 [N,2])");
     m.def("ratio_filter", &ratio_filter, py::arg("idx"), py::arg("dist"),
           "Lowe ratio 0.75 filter: (queryIdx, second trainIdx, first trainIdx) of the kept rows");
+    m.def("profile", &profile, py::arg("enable"),
+          "Switch per-kernel / host-phase timing of this module's calls on or off (and clear the totals)");
+    m.def("profile_read", &profile_read,
+          "{'kernel_ms': {kernel: (ms, launches)}, 'host_us': {h2d, enqueue, wait, d2h}} since profile(True)");
 }
