@@ -103,7 +103,7 @@ int orbamd_ctx_set_detector(orbamd_ctx* ctx, int threshold, int arc, int wrap, i
  * (ORBAMD_K_*), the summed milliseconds and launch count since the last reset. */
 #define ORBAMD_K_BGR2GRAY   0
 #define ORBAMD_K_FAST       1
-#define ORBAMD_K_ROWCOUNT   2
+#define ORBAMD_K_ROWCOUNT   2   /* the fill that zeroes the per-row corner totals before the detector runs */
 #define ORBAMD_K_ROWSCAN    3
 #define ORBAMD_K_EMIT       4
 #define ORBAMD_K_DESCRIBE   5
@@ -189,7 +189,20 @@ int orbamd_knn2(orbamd_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int
 int orbamd_ratio_filter(orbamd_ctx* ctx, const int32_t* idx, const int32_t* dist, int nq,
                         int32_t* good_q, int32_t* good_t2, int32_t* good_t1, int* m_out);
 
+/* orbamd_knn2 followed by orbamd_ratio_filter on its output, in one call with one wait for the device: the
+ * knnMatch + ratio loop of reference views.py:162-171.  idx_out / dist_out as orbamd_knn2 (always
+ * written); good_q / good_t2 / good_t1 as orbamd_ratio_filter, *m_out rows.  When some query has fewer
+ * than two neighbours (nt < 2) *m_out is -1 and the status ORBAMD_E_BADARG, as orbamd_ratio_filter
+ * reports it.  The three lists must hold nq entries. */
+int orbamd_knn2_ratio(orbamd_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                      int32_t* idx_out, int32_t* dist_out, int32_t* good_q, int32_t* good_t2,
+                      int32_t* good_t1, int* m_out);
+
 /* ---- frame batches, device pointers ------------------------------------------------------ */
+
+/* Alignment: image pointers may have any alignment (16-byte-aligned frames whose width is a multiple of 16
+ * take the fastest kernels).  Descriptor pointers handed to the orbamd_knn2*_dev calls must be 16-byte
+ * aligned (rows are fetched 16 bytes at a time); a misaligned one is ORBAMD_E_BADARG. */
 
 /* Synthetic gray frames written straight into device memory: frame i of the call is frame
  * (first_frame + i) of the seeded scene (see visual_slam_amd/synth.py for the definition).

@@ -276,6 +276,35 @@ def test_host_frame_stager_equals_whole_batch(eng, bgr):
     assert seen == F
 
 
+@pytest.mark.parametrize("bgr", [False, True])
+def test_frame_file_through_the_stager_equals_the_in_memory_path(eng, tmp_path, bgr):
+    """A Y4M file on disk -> FrameFile -> pinned chunks -> device: the same features and matches as the
+    frames handed over from memory (stand-in for cv.VideoCapture + cap.read(), reference main.py:80, views.py:81)."""
+    import torch
+    from visual_slam_amd import frames as fsrc
+    from visual_slam_amd.staging import HostFrameStager
+    H, W, F = 96, 144, 9
+    gray = [synth.synth_frame(H, W, 500 + f, cell=12) for f in range(F)]
+    path = str(tmp_path / "clip.y4m")
+    fsrc.write_y4m(path, gray, colourspace="420jpeg")
+    ex = [oracle.c.extract_gray(g) for g in gray]
+    st = HostFrameStager(eng, H, W, chunk=4, bgr=bgr)
+    seen = 0
+    with fsrc.FrameFile(path, bgr=bgr) as src:
+        for ch in st.run(src):
+            torch.cuda.synchronize()
+            for i in range(ch.frames):
+                f = ch.first + i
+                kp, desc, vidx = ch.features.frame(i)
+                assert np.array_equal(bits(kp), bits(ex[f][0])) and np.array_equal(desc, ex[f][1])
+                if f:
+                    idx, dist, _ = ch.matches.pair(i, len(desc))
+                    eidx, edist = oracle.c.knn2(ex[f][1], ex[f - 1][1])
+                    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+            seen += ch.frames
+        assert seen == F and src.index == F
+
+
 def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     import torch
     from visual_slam_amd.engine import OrbEngine

@@ -215,6 +215,46 @@ def test_ratio_filter_matches_oracle(gctx):
         gctx.ratio_filter(np.array([[0, -1]], np.int32), np.array([[5, -1]], np.int32))
 
 
+def test_knn2_ratio_is_knn2_then_ratio_filter(gctx, matcher):
+    """The one-trip call gives what the two separate calls give (and the oracle), also interleaved with
+    extract / fetch, whose pinned result rows it shares a staging buffer with."""
+    q = synth.synth_descriptors(2100, 41)
+    t = synth.synth_descriptors(1900, 42)
+    t[:600] = q[:600]
+    t[:600:5, 3] ^= 0x11
+    eidx, edist = oracle.c.knn2(q, t)
+    exp = oracle.c.ratio_filter(eidx, edist)
+    img = make_test_image(120, 160, 77)
+    want = oracle.c.extract_gray(img)
+    for _ in range(2):
+        idx, dist, gq, g2, g1 = gctx.knn2_ratio(q, t)
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        assert np.array_equal(gq, exp[0]) and np.array_equal(g2, exp[1]) and np.array_equal(g1, exp[2])
+        assert_extract_equal(gctx.extract_gray(img), want)
+    assert 0 < len(exp[0]) < 2100
+    # one train row: every query lacks a second neighbour, as the reference's unpacking would raise
+    with pytest.raises(ValueError):
+        gctx.knn2_ratio(q[:10], t[:1])
+    idx, dist, gq, g2, g1 = gctx.knn2_ratio(q[:0], t)
+    assert idx.shape == (0, 2) and len(gq) == 0
+
+
+def test_fetch_after_a_matcher_call_still_returns_the_last_extract(gctx):
+    """orbamd_fetch may be called late: the matcher reuses the pinned buffer that held the speculative copy
+    of the extract's rows, and fetch then goes back to the device."""
+    import ctypes
+    from visual_slam_amd import _lib
+    img = make_test_image(200, 320, 5)
+    want = oracle.c.extract_gray(img)
+    L = _lib.lib()
+    n, nv = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.orbamd_extract_gray(gctx._h, _lib._np_ptr(img), 200, 320, ctypes.byref(n), ctypes.byref(nv)) == 0
+    q = synth.synth_descriptors(300, 1)
+    gctx.knn2(q, q)
+    got = gctx._fetch(n.value, nv.value)
+    assert_extract_equal(got, want)
+
+
 @pytest.mark.parametrize("H,W", [(67, 1000), (50, 530), (40, 259), (64, 272), (35, 4099)])
 def test_extract_on_widths_that_exercise_every_staging_path(gctx, H, W):
     """W % 16 == 0 takes 16-byte staging loads, W % 4 == 0 dword loads, anything else the byte path;

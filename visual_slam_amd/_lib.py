@@ -53,6 +53,7 @@ SIGNATURES = {
     "orbamd_fetch": (_int, [_c_ctx, _vp, _vp, _vp]),
     "orbamd_knn2": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp]),
     "orbamd_ratio_filter": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _vp, _intp]),
+    "orbamd_knn2_ratio": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _intp]),
     "orbamd_synth_frames_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, ctypes.c_uint32, _int, _int]),
     "orbamd_synth_textured_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _int, ctypes.c_uint32]),
     "orbamd_bgr2gray_dev": (_int, [_c_ctx, _vp, _int, _int, _int, _vp]),
@@ -287,6 +288,24 @@ class Context:
         self._chk(lib().orbamd_knn2(self._h, _np_ptr(q), len(q), _np_ptr(t), len(t), _np_ptr(idx), _np_ptr(dist)),
                   "knn2")
         return idx, dist
+
+    def knn2_ratio(self, q, t):
+        """knn2 + ratio_filter in one call: (idx, dist, good_q, good_t2, good_t1)."""
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq = len(q)
+        idx = np.empty((nq, 2), np.int32)
+        dist = np.empty((nq, 2), np.int32)
+        gq, g2, g1 = (np.empty(max(nq, 1), np.int32) for _ in range(3))
+        m = ctypes.c_int(0)
+        st = self._chk(lib().orbamd_knn2_ratio(self._h, _np_ptr(q), nq, _np_ptr(t), len(t), _np_ptr(idx), _np_ptr(dist),
+                                               _np_ptr(gq), _np_ptr(g2), _np_ptr(g1), ctypes.byref(m)),
+                       "knn2_ratio", allow=(E_BADARG,))
+        if st == E_BADARG:
+            if m.value == -1:
+                raise ValueError("not enough values to unpack (expected 2)")
+            raise OrbAmdError(st, "knn2_ratio")
+        return idx, dist, gq[:m.value].copy(), g2[:m.value].copy(), g1[:m.value].copy()
 
     def ratio_filter(self, idx, dist):
         idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 2)

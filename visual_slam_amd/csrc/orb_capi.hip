@@ -66,7 +66,8 @@ struct orbamd_ctx {
     int single_cap = 16384;
     int guess_rows = 8192;
     int spec_n = 0, spec_nv = 0;
-    PinnedBuf in_stage, out_kp, out_desc, out_vidx, mt_stage;
+    size_t off_kp = 0, off_desc = 0, off_vidx = 0;   // where those rows sit in out_block
+    PinnedBuf in_stage, out_block, mt_stage;
     bool stage_h2d = true;
     double host_us[ORBAMD_HT_COUNT] = {0};
 
@@ -147,27 +148,6 @@ struct HostPhase {
     }
 };
 
-// Host -> device for a caller's (pageable) array.  Staged: copied piece by piece into pinned memory owned by
-// the context, each piece's DMA in flight while the next is being copied, so that nothing waits for the
-// device.  The pinned buffer is reused by the next call, which is why every host-pointer entry point ends
-// with a wait for the stream.
-int upload(orbamd_ctx* c, void* dst, const void* src, size_t bytes, PinnedBuf& stage)
-{
-    HostPhase hp(c, ORBAMD_HT_H2D);
-    if (!c->stage_h2d) {
-        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-        return ORBAMD_OK;
-    }
-    CHK(ensure_pinned(c, stage, bytes));
-    const size_t piece = 1u << 19;
-    for (size_t o = 0; o < bytes; o += piece) {
-        const size_t nb = bytes - o < piece ? bytes - o : piece;
-        memcpy(stage.p + o, (const uint8_t*)src + o, nb);
-        HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + o, stage.p + o, nb, hipMemcpyHostToDevice, c->stream));
-    }
-    return ORBAMD_OK;
-}
-
 hipEvent_t get_event(orbamd_ctx* c)
 {
     if (!c->pool.empty()) {
@@ -215,6 +195,56 @@ int post_launch(orbamd_ctx* c, const char* what)
     return ORBAMD_OK;
 }
 
+// Host -> device for a caller's (pageable) array: copied piece by piece into pinned memory owned by the
+// context, each piece picked up from there by a copy KERNEL (pinned memory is mapped into the device's address
+// space) while the host copies the next piece.  No copy-engine transfer is involved, so nothing on the stream
+// waits for another queue.  The pinned buffer is reused by the next call, which is why every host-pointer
+// entry point ends with a wait for the stream.  dst must be 16-byte aligned.
+constexpr size_t INGEST_PIECE = 3u << 18;    // 768 KiB
+
+int upload(orbamd_ctx* c, void* dst, const void* src, size_t bytes, PinnedBuf& stage, size_t stage_off = 0)
+{
+    HostPhase hp(c, ORBAMD_HT_H2D);
+    if (!c->stage_h2d) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return ORBAMD_OK;
+    }
+    CHK(ensure_pinned(c, stage, stage_off + bytes));
+    for (size_t o = 0; o < bytes; o += INGEST_PIECE) {
+        const size_t nb = bytes - o < INGEST_PIECE ? bytes - o : INGEST_PIECE;
+        memcpy(stage.p + stage_off + o, (const uint8_t*)src + o, nb);
+        launch_copy_bytes(stage.p + stage_off + o, (uint8_t*)dst + o, nb, c->stream);
+    }
+    return post_launch(c, "copy16_kernel");
+}
+
+// BGR frame -> gray in device memory: staged like upload(), but each piece is converted straight out of
+// pinned memory, so the BGR pixels never exist in device memory.
+int upload_bgr_as_gray(orbamd_ctx* c, uint8_t* d_gray, const uint8_t* bgr, size_t npix)
+{
+    if (!c->stage_h2d) {
+        CHK(ensure(c, c->bgr, npix * 3));
+        {
+            HostPhase hp(c, ORBAMD_HT_H2D);
+            HIPCHK(c, hipMemcpyAsync(c->bgr.p, bgr, npix * 3, hipMemcpyHostToDevice, c->stream));
+        }
+        Timed t(c, ORBAMD_K_BGR2GRAY);
+        launch_bgr2gray((const uint8_t*)c->bgr.p, d_gray, (long)npix, c->stream);
+        return ORBAMD_OK;
+    }
+    HostPhase hp(c, ORBAMD_HT_H2D);
+    CHK(ensure_pinned(c, c->in_stage, npix * 3));
+    const size_t piece = INGEST_PIECE / 3;              // pixels per piece, a multiple of 4
+    static_assert((INGEST_PIECE / 3) % 4 == 0, "pieces start on a dword of both the BGR and the gray array");
+    for (size_t o = 0; o < npix; o += piece) {
+        const size_t np = npix - o < piece ? npix - o : piece;
+        memcpy(c->in_stage.p + 3 * o, bgr + 3 * o, 3 * np);
+        Timed t(c, ORBAMD_K_BGR2GRAY);
+        launch_bgr2gray(c->in_stage.p + 3 * o, d_gray + o, (long)np, c->stream);
+    }
+    return ORBAMD_OK;
+}
+
 int drain_timing(orbamd_ctx* c)
 {
     if (c->pending.empty()) return ORBAMD_OK;
@@ -239,6 +269,9 @@ int enter(orbamd_ctx* c)
     return ORBAMD_OK;
 }
 
+// Descriptor rows are fetched 16 bytes at a time.
+bool misaligned16(const void* p) { return ((uintptr_t)p & 15) != 0; }
+
 int check_image(int H, int W)
 {
     // H * MW and H * W must stay well inside 32-bit grid and index arithmetic per frame.
@@ -256,8 +289,11 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     FrameSet fs{d_gray, frames, H, W};
     const bool reference_detector = c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms;
     if (!reference_detector) CHK(ensure(c, c->score, (size_t)frames * H * W));
-    // (the row totals start from zero; the fill is not part of the kernel's timing bracket)
-    HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
+    {
+        // the row totals start from zero; the fill is timed under its own kind, not as part of the detector
+        Timed t(c, ORBAMD_K_ROWCOUNT);
+        HIPCHK(c, hipMemsetAsync(c->rowcnt.p, 0, (size_t)frames * H * sizeof(int2), c->stream));
+    }
     {
         Timed t(c, ORBAMD_K_FAST);
         if (reference_detector) launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
@@ -412,21 +448,29 @@ int extract_resident(orbamd_ctx* c, int H, int W, int* n_out, int* nv_out)
         }
         const int g = c->guess_rows < cap ? c->guess_rows : cap;
         {
+            // one kernel writes the counts and the live rows (at most g of each) into pinned host memory
             HostPhase hp(c, ORBAMD_HT_D2H);
-            CHK(ensure_pinned(c, c->out_kp, (size_t)g * 7 * sizeof(float)));
-            CHK(ensure_pinned(c, c->out_desc, (size_t)g * 32));
-            CHK(ensure_pinned(c, c->out_vidx, (size_t)g * sizeof(int32_t)));
-            HIPCHK(c, hipMemcpyAsync(c->h_counts, c->counts.p, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->out_kp.p, c->kp7.p, (size_t)g * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->out_desc.p, c->desc.p, (size_t)g * 32, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->out_vidx.p, c->vidx.p, (size_t)g * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            c->off_kp = 64;
+            c->off_desc = c->off_kp + (((size_t)g * 28 + 15) & ~(size_t)15);
+            c->off_vidx = c->off_desc + (size_t)g * 32;
+            CHK(ensure_pinned(c, c->out_block, c->off_vidx + (size_t)g * 4));
+            const int32_t* dc = (const int32_t*)c->counts.p;
+            uint8_t* const h = c->out_block.p;
+            EgressArgs e{};
+            e.nseg = 4;
+            e.seg[0] = {(const uint32_t*)c->counts.p, (uint32_t*)h, nullptr, 0, 2};
+            e.seg[1] = {(const uint32_t*)c->kp7.p, (uint32_t*)(h + c->off_kp), dc, 7, g * 7};
+            e.seg[2] = {(const uint32_t*)c->desc.p, (uint32_t*)(h + c->off_desc), dc + 1, 8, g * 8};
+            e.seg[3] = {(const uint32_t*)c->vidx.p, (uint32_t*)(h + c->off_vidx), dc + 1, 1, g};
+            launch_egress(e, c->stream);
+            CHK(post_launch(c, "egress_kernel"));
         }
         {
             HostPhase hp(c, ORBAMD_HT_WAIT);
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        n = c->h_counts[0];
-        nv = c->h_counts[1];
+        n = reinterpret_cast<const int32_t*>(c->out_block.p)[0];
+        nv = reinterpret_cast<const int32_t*>(c->out_block.p)[1];
         if (n > ORBAMD_MAX_CAP) return ORBAMD_E_CAPACITY;
         c->spec_n = g;
         c->spec_nv = g;
@@ -532,7 +576,7 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
-    PinnedBuf* pins[] = {&c->in_stage, &c->out_kp, &c->out_desc, &c->out_vidx, &c->mt_stage};
+    PinnedBuf* pins[] = {&c->in_stage, &c->out_block, &c->mt_stage};
     for (PinnedBuf* b : pins)
         if (b->p) (void)hipHostFree(b->p);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -552,13 +596,22 @@ int orbamd_ctx_reserve(orbamd_ctx* c, int frames, int H, int W, int cap)
     CHK(ensure(c, c->kpxy, (size_t)frames * cap * sizeof(int2)));
     CHK(ensure(c, c->kpslot, (size_t)frames * cap * sizeof(int32_t)));
     // the matcher's partial keys, for the consecutive pairs of such a batch (either kernel family)
+    // (and for the single pair of orbamd_knn2_cross_dev, which is split further than the pairs of a large batch)
     if (cap <= ORBAMD_MAX_TRAIN) {
-        const int npairs = frames > 1 ? frames - 1 : 1;
-        int splits = choose_splits(cap, cap, npairs, 512, 1024);
-        const int sv = choose_splits(cap, cap, npairs, 256, 2048);
-        splits = splits > sv ? splits : sv;
-        if (splits > 1) CHK(ensure(c, c->partial, (size_t)npairs * splits * cap * 2 * sizeof(uint32_t)));
+        size_t need = 0;
+        const int batch_pairs = frames > 1 ? frames - 1 : 1;
+        for (int npairs : {batch_pairs, 1}) {
+            int splits = choose_splits(cap, cap, npairs, 512, 1024);
+            const int sv = choose_splits(cap, cap, npairs, 256, 2048);
+            splits = splits > sv ? splits : sv;
+            const size_t b = splits > 1 ? (size_t)npairs * splits * cap * 2 * sizeof(uint32_t) : 0;
+            need = b > need ? b : need;
+        }
+        if (need) CHK(ensure(c, c->partial, need));
     }
+    // the score map of the detector extension, when one is selected
+    if (!(c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms))
+        CHK(ensure(c, c->score, (size_t)frames * H * W));
     return ORBAMD_OK;
 }
 
@@ -764,13 +817,8 @@ int orbamd_extract_bgr(orbamd_ctx* c, const uint8_t* bgr, int H, int W, int* n_o
     if (!bgr) return ORBAMD_E_BADARG;
     CHK(check_image(H, W));
     const size_t npix = (size_t)H * W;
-    CHK(ensure(c, c->bgr, npix * 3));
     CHK(ensure(c, c->gray, npix));
-    CHK(upload(c, c->bgr.p, bgr, npix * 3, c->in_stage));
-    {
-        Timed t(c, ORBAMD_K_BGR2GRAY);
-        launch_bgr2gray((const uint8_t*)c->bgr.p, (uint8_t*)c->gray.p, (long)npix, c->stream);
-    }
+    CHK(upload_bgr_as_gray(c, (uint8_t*)c->gray.p, bgr, npix));
     CHK(post_launch(c, "bgr2gray_kernel"));
     return extract_resident(c, H, W, n_out, nv_out);
 }
@@ -785,15 +833,15 @@ int orbamd_fetch(orbamd_ctx* c, float* kp7_out, uint8_t* desc_out, int32_t* vali
     // outgrew the guess is fetched from the device
     bool wait = false;
     if (n > 0 && kp7_out) {
-        if (n <= c->spec_n) memcpy(kp7_out, c->out_kp.p, (size_t)n * 7 * sizeof(float));
+        if (n <= c->spec_n) memcpy(kp7_out, c->out_block.p + c->off_kp, (size_t)n * 7 * sizeof(float));
         else {
             HIPCHK(c, hipMemcpyAsync(kp7_out, c->kp7.p, (size_t)n * 7 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
             wait = true;
         }
     }
     if (nv > 0 && nv <= c->spec_nv) {
-        if (desc_out) memcpy(desc_out, c->out_desc.p, (size_t)nv * 32);
-        if (valid_idx_out) memcpy(valid_idx_out, c->out_vidx.p, (size_t)nv * sizeof(int32_t));
+        if (desc_out) memcpy(desc_out, c->out_block.p + c->off_desc, (size_t)nv * 32);
+        if (valid_idx_out) memcpy(valid_idx_out, c->out_block.p + c->off_vidx, (size_t)nv * sizeof(int32_t));
     } else if (nv > 0) {
         if (desc_out)
             HIPCHK(c, hipMemcpyAsync(desc_out, c->desc.p, (size_t)nv * 32, hipMemcpyDeviceToHost, c->stream));
@@ -817,23 +865,10 @@ int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     CHK(ensure(c, c->t, (size_t)nt * 32));
     CHK(ensure(c, c->idx, (size_t)nq * 2 * sizeof(int32_t)));
     CHK(ensure(c, c->dist, (size_t)nq * 2 * sizeof(int32_t)));
-    {
-        // both descriptor sets through one pinned staging buffer (query rows first)
-        HostPhase hp(c, ORBAMD_HT_H2D);
-        if (c->stage_h2d) {
-            CHK(ensure_pinned(c, c->mt_stage, (size_t)(nq + nt) * 32));
-            memcpy(c->mt_stage.p, q, (size_t)nq * 32);
-            HIPCHK(c, hipMemcpyAsync(c->q.p, c->mt_stage.p, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-            if (nt > 0) {
-                memcpy(c->mt_stage.p + (size_t)nq * 32, t, (size_t)nt * 32);
-                HIPCHK(c, hipMemcpyAsync(c->t.p, c->mt_stage.p + (size_t)nq * 32, (size_t)nt * 32,
-                                         hipMemcpyHostToDevice, c->stream));
-            }
-        } else {
-            HIPCHK(c, hipMemcpyAsync(c->q.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
-            if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->t.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
-        }
-    }
+    // both descriptor sets through one pinned staging buffer (query rows first)
+    CHK(ensure_pinned(c, c->mt_stage, (size_t)(nq + nt) * 32));
+    CHK(upload(c, c->q.p, q, (size_t)nq * 32, c->mt_stage, 0));
+    if (nt > 0) CHK(upload(c, c->t.p, t, (size_t)nt * 32, c->mt_stage, (size_t)nq * 32));
     Knn2Args a{};
     a.qdesc = (const uint8_t*)c->q.p;
     a.tdesc = (const uint8_t*)c->t.p;
@@ -847,29 +882,98 @@ int orbamd_knn2(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
         HostPhase hp(c, ORBAMD_HT_ENQUEUE);
         CHK(run_knn2(c, a));
     }
+    // results to pinned memory by a kernel behind the matcher, one wait, then into the caller's arrays
     const size_t ob = (size_t)nq * 2 * sizeof(int32_t);
-    if (c->stage_h2d) {
-        // results to pinned memory behind the kernel, one wait, then into the caller's arrays
-        CHK(ensure_pinned(c, c->out_kp, 2 * ob));
-        {
-            HostPhase hp(c, ORBAMD_HT_D2H);
-            HIPCHK(c, hipMemcpyAsync(c->out_kp.p, c->idx.p, ob, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->out_kp.p + ob, c->dist.p, ob, hipMemcpyDeviceToHost, c->stream));
-        }
-        {
-            HostPhase hp(c, ORBAMD_HT_WAIT);
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
+    CHK(ensure_pinned(c, c->out_block, 2 * ob));
+    c->spec_n = c->spec_nv = 0;          // the block no longer holds the last extract's rows
+    {
         HostPhase hp(c, ORBAMD_HT_D2H);
-        memcpy(idx_out, c->out_kp.p, ob);
-        memcpy(dist_out, c->out_kp.p + ob, ob);
-        c->spec_n = c->spec_nv = 0;      // the staging buffer no longer holds the last extract's rows
-        return ORBAMD_OK;
+        EgressArgs e{};
+        e.nseg = 2;
+        e.seg[0] = {(const uint32_t*)c->idx.p, (uint32_t*)c->out_block.p, nullptr, 0, nq * 2};
+        e.seg[1] = {(const uint32_t*)c->dist.p, (uint32_t*)(c->out_block.p + ob), nullptr, 0, nq * 2};
+        launch_egress(e, c->stream);
+        CHK(post_launch(c, "egress_kernel"));
+    }
+    {
+        HostPhase hp(c, ORBAMD_HT_WAIT);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HostPhase hp(c, ORBAMD_HT_D2H);
-    HIPCHK(c, hipMemcpyAsync(idx_out, c->idx.p, ob, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dist_out, c->dist.p, ob, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(idx_out, c->out_block.p, ob);
+    memcpy(dist_out, c->out_block.p + ob, ob);
+    return ORBAMD_OK;
+}
+
+int orbamd_knn2_ratio(orbamd_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx_out,
+                      int32_t* dist_out, int32_t* good_q, int32_t* good_t2, int32_t* good_t1, int* m_out)
+{
+    CHK(enter(c));
+    if (nq < 0 || nt < 0 || nt >= ORBAMD_MAX_TRAIN || !m_out) return ORBAMD_E_BADARG;
+    *m_out = 0;
+    if (nq == 0) return ORBAMD_OK;
+    if (!q || !idx_out || !dist_out || !good_q || !good_t2 || !good_t1 || (nt > 0 && !t)) return ORBAMD_E_BADARG;
+    const size_t b1 = (size_t)nq * sizeof(int32_t), b2 = 2 * b1;
+    CHK(ensure(c, c->q, (size_t)nq * 32));
+    CHK(ensure(c, c->t, (size_t)nt * 32));
+    CHK(ensure(c, c->idx, b2));
+    CHK(ensure(c, c->dist, b2));
+    CHK(ensure(c, c->rq, b1));
+    CHK(ensure(c, c->rt2, b1));
+    CHK(ensure(c, c->rt1, b1));
+    CHK(ensure(c, c->rcount, 16));
+    CHK(ensure_pinned(c, c->mt_stage, (size_t)(nq + nt) * 32));
+    CHK(ensure_pinned(c, c->out_block, 64 + 2 * b2 + 3 * b1));
+    CHK(upload(c, c->q.p, q, (size_t)nq * 32, c->mt_stage, 0));
+    if (nt > 0) CHK(upload(c, c->t.p, t, (size_t)nt * 32, c->mt_stage, (size_t)nq * 32));
+    {
+        HostPhase hp(c, ORBAMD_HT_ENQUEUE);
+        Knn2Args a{};
+        a.qdesc = (const uint8_t*)c->q.p;
+        a.tdesc = (const uint8_t*)c->t.p;
+        a.npairs = 1;
+        a.cap = nq;
+        a.nq_fixed = nq;
+        a.nt_fixed = nt;
+        a.idx = (int32_t*)c->idx.p;
+        a.dist = (int32_t*)c->dist.p;
+        CHK(run_knn2(c, a));
+        {
+            Timed tm(c, ORBAMD_K_RATIO);
+            launch_ratio_compact((const int32_t*)c->idx.p, (const int32_t*)c->dist.p, nq, (int32_t*)c->rq.p,
+                                 (int32_t*)c->rt2.p, (int32_t*)c->rt1.p, (int32_t*)c->rcount.p, c->stream);
+        }
+        CHK(post_launch(c, "ratio_compact_kernel"));
+    }
+    uint8_t* const h = c->out_block.p;   // count | idx | dist | good_q | good_t2 | good_t1
+    c->spec_n = c->spec_nv = 0;          // the block no longer holds the last extract's rows
+    {
+        HostPhase hp(c, ORBAMD_HT_D2H);
+        const int32_t* rc = (const int32_t*)c->rcount.p;
+        EgressArgs e{};
+        e.nseg = 6;
+        e.seg[0] = {(const uint32_t*)c->rcount.p, (uint32_t*)h, nullptr, 0, 1};
+        e.seg[1] = {(const uint32_t*)c->idx.p, (uint32_t*)(h + 64), nullptr, 0, nq * 2};
+        e.seg[2] = {(const uint32_t*)c->dist.p, (uint32_t*)(h + 64 + b2), nullptr, 0, nq * 2};
+        e.seg[3] = {(const uint32_t*)c->rq.p, (uint32_t*)(h + 64 + 2 * b2), rc, 1, nq};
+        e.seg[4] = {(const uint32_t*)c->rt2.p, (uint32_t*)(h + 64 + 2 * b2 + b1), rc, 1, nq};
+        e.seg[5] = {(const uint32_t*)c->rt1.p, (uint32_t*)(h + 64 + 2 * b2 + 2 * b1), rc, 1, nq};
+        launch_egress(e, c->stream);
+        CHK(post_launch(c, "egress_kernel"));
+    }
+    {
+        HostPhase hp(c, ORBAMD_HT_WAIT);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    HostPhase hp(c, ORBAMD_HT_D2H);
+    memcpy(idx_out, h + 64, b2);
+    memcpy(dist_out, h + 64 + b2, b2);
+    const int m = reinterpret_cast<const int32_t*>(h)[0];
+    *m_out = m;
+    if (m < 0) return ORBAMD_E_BADARG;   // some query has fewer than two neighbours
+    memcpy(good_q, h + 64 + 2 * b2, (size_t)m * 4);
+    memcpy(good_t2, h + 64 + 2 * b2 + b1, (size_t)m * 4);
+    memcpy(good_t1, h + 64 + 2 * b2 + 2 * b1, (size_t)m * 4);
     return ORBAMD_OK;
 }
 
@@ -973,6 +1077,7 @@ int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d
         npairs < 0 || npairs > 65535)
         return ORBAMD_E_BADARG;
     if (!d_pairs && npairs > frames - 1) return ORBAMD_E_BADARG;
+    if (misaligned16(d_desc)) return ORBAMD_E_BADARG;
     if (npairs == 0) return ORBAMD_OK;
     Knn2Args a{};
     a.qdesc = d_desc;
@@ -1014,7 +1119,7 @@ int orbamd_knn2_cross_dev(orbamd_ctx* c, const uint8_t* d_qdesc, const int32_t* 
 {
     CHK(enter(c));
     if (!d_qdesc || !d_qcounts || !d_tdesc || !d_tcounts || !d_idx || !d_dist || qframe < 0 || tframe < 0 ||
-        cap <= 0 || cap > ORBAMD_MAX_TRAIN)
+        cap <= 0 || cap > ORBAMD_MAX_TRAIN || misaligned16(d_qdesc) || misaligned16(d_tdesc))
         return ORBAMD_E_BADARG;
     Knn2Args a{};
     a.qdesc = d_qdesc;
@@ -1038,6 +1143,7 @@ int orbamd_knn2_dev(orbamd_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_
     if (nq < 0 || nt < 0 || nt >= ORBAMD_MAX_TRAIN) return ORBAMD_E_BADARG;
     if (nq == 0) return ORBAMD_OK;
     if (!d_q || !d_idx || !d_dist || (nt > 0 && !d_t)) return ORBAMD_E_BADARG;
+    if (misaligned16(d_q) || misaligned16(d_t)) return ORBAMD_E_BADARG;
     Knn2Args a{};
     a.qdesc = d_q;
     a.tdesc = d_t ? d_t : d_q;
@@ -1062,6 +1168,7 @@ int orbamd_knn2_dev_noalloc(orbamd_ctx* c, const uint8_t* d_q, int nq, const uin
     }
     if (nq == 0) return ORBAMD_OK;
     if (!d_q || !d_idx || !d_dist || (nt > 0 && !d_t)) return ORBAMD_E_BADARG;
+    if (misaligned16(d_q) || misaligned16(d_t)) return ORBAMD_E_BADARG;
     if (!c->noalloc_scratch) return ORBAMD_E_STATE;
     Knn2Args a{};
     a.qdesc = d_q;

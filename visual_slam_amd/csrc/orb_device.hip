@@ -155,6 +155,56 @@ void launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long npix, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ingest / egress for the single-frame, host-pointer calls.  Pinned host memory is mapped into the device's
+// address space, so a kernel can read a staged input or write results there directly; compared with
+// copy-engine transfers this removes a queue-to-queue synchronisation (10 - 20 us each on MI355X) per
+// transfer from a call that is all latency.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16,
+                                                     long nbytes)
+{
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    // tail bytes (nbytes not a multiple of 16)
+    const long done = n16 * 16;
+    if (blockIdx.x == 0 && done + threadIdx.x < nbytes)
+        reinterpret_cast<uint8_t*>(dst)[done + threadIdx.x] = reinterpret_cast<const uint8_t*>(src)[done + threadIdx.x];
+}
+
+void launch_copy_bytes(const void* src, void* dst, size_t nbytes, hipStream_t s)
+{
+    const long n16 = (long)(nbytes >> 4);
+    long blocks = (n16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16,
+                       (long)nbytes);
+}
+
+__global__ __launch_bounds__(256) void egress_kernel(EgressArgs a)
+{
+    const long stride = (long)gridDim.x * 256;
+    for (int k = 0; k < a.nseg; ++k) {
+        const EgressSeg sg = a.seg[k];
+        long n = sg.max_dwords;
+        if (sg.count) {
+            long c = sg.count[0];
+            c = c < 0 ? 0 : c * sg.count_mul;
+            n = c < n ? c : n;
+        }
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) sg.dst[i] = sg.src[i];
+    }
+}
+
+void launch_egress(const EgressArgs& a, hipStream_t s)
+{
+    long total = 0;
+    for (int k = 0; k < a.nseg; ++k) total += a.seg[k].max_dwords;
+    long blocks = (total + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(egress_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic frames (definition: visual_slam_amd/synth.py).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x)
@@ -742,8 +792,10 @@ void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_
     hipLaunchKernelGGL(rowscan_kernel, dim3(fs.frames), dim3(256), 0, s, rowcnt, fs.H, rowoff, counts);
 }
 
-constexpr int EMIT_ROWS = 64;       // rows per wave: one row's count and offset per lane
 constexpr int EMIT_AHEAD = 4;       // rows whose mask words are fetched together
+// EMIT_ROWS = rows per wave (one row's count and offset per lane): 64 for batches; small launches (a single
+// frame) use 8 so that the rows spread over enough waves.
+template <int EMIT_ROWS>
 __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ mask, int H, int W,
                                                    int MW, long nrows, const int2* __restrict__ rowcnt,
                                                    const int2* __restrict__ rowoff, int cap,
@@ -757,7 +809,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint32_t* __restrict__ 
     const long r0 = ((long)blockIdx.x * 4 + wave_id()) * EMIT_ROWS;
     if (r0 >= nrows) return;
     const int lane = lane_id();
-    const bool have = r0 + lane < nrows;
+    const bool have = lane < EMIT_ROWS && r0 + lane < nrows;
     const int2 rc_l = have ? rowcnt[r0 + lane] : make_int2(0, 0);
     const int2 off_l = have ? rowoff[r0 + lane] : make_int2(0, 0);
     // frame and image row of every lane's row: one division for the 64 rows (nrows < 2^31)
@@ -827,8 +879,12 @@ void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, c
                  int cap, int2* kpxy, int32_t* kpslot, int32_t* counts, hipStream_t s)
 {
     long nrows = (long)fs.frames * fs.H;
-    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((nrows + 4 * EMIT_ROWS - 1) / (4 * EMIT_ROWS))), dim3(256), 0, s, mask, fs.H, fs.W,
-                       mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot, counts);
+    if (nrows >= 16384)
+        hipLaunchKernelGGL(emit_kernel<64>, dim3((unsigned)((nrows + 4 * 64 - 1) / (4 * 64))), dim3(256), 0, s, mask, fs.H,
+                           fs.W, mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot, counts);
+    else
+        hipLaunchKernelGGL(emit_kernel<8>, dim3((unsigned)((nrows + 4 * 8 - 1) / (4 * 8))), dim3(256), 0, s, mask, fs.H,
+                           fs.W, mask_words(fs.W), nrows, rowcnt, rowoff, cap, kpxy, kpslot, counts);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -24,6 +24,22 @@ struct ExtractBuffers {
 
 // Kernel launchers (enqueue on `s`, no synchronisation, no allocation).
 void launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long npix, hipStream_t s);
+// nbytes from src to dst by a kernel; both 16-byte aligned, either may be pinned host memory.
+void launch_copy_bytes(const void* src, void* dst, size_t nbytes, hipStream_t s);
+// Up to 6 dword segments copied by one kernel (results -> pinned host memory): segment k moves
+// min(max_dwords, count ? max(count[0], 0) * count_mul : max_dwords) dwords, count read on the device.
+struct EgressSeg {
+    const uint32_t* src;
+    uint32_t* dst;
+    const int32_t* count;
+    int count_mul;
+    int max_dwords;
+};
+struct EgressArgs {
+    EgressSeg seg[6];
+    int nseg;
+};
+void launch_egress(const EgressArgs& a, hipStream_t s);
 void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint32_t seed, int cell,
                   int density_thr, hipStream_t s);
 // Also accumulates rowcnt[frame][y] = (corners, corners with a descriptor); rowcnt must be zero.

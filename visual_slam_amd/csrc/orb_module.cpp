@@ -8,7 +8,7 @@
 // (src/main_interface.cpp:57-65, :89-98).
 //
 // Added entry points (the reference has no matcher in its module; it calls OpenCV from Python at
-// views.py:162): extract_gray, extract_indexed, knn_match2, ratio_filter; profile / profile_read for measurement.
+// views.py:162): extract_gray, extract_indexed, knn_match2, ratio_filter, match_ratio; profile / profile_read for measurement.
 //
 // This translation unit contains no image arithmetic; it only moves buffers through the C ABI.
 #include <pybind11/numpy.h>
@@ -162,6 +162,35 @@ py::tuple knn_match2(const py::array& d1, const py::array& d2)
     return py::make_tuple(idx, dist);
 }
 
+// knn_match2 + ratio_filter with one trip to the device: the knnMatch call and the ratio loop of reference
+// views.py:162-171 together.
+py::tuple match_ratio(const py::array& d1, const py::array& d2)
+{
+    py::array_t<uint8_t> q = as_desc(d1, "query descriptors");
+    py::array_t<uint8_t> t = as_desc(d2, "train descriptors");
+    const int nq = (int)q.shape(0), nt = (int)t.shape(0);
+    using Shape = std::vector<py::ssize_t>;
+    py::array_t<int32_t> idx(Shape{nq, 2}), dist(Shape{nq, 2});
+    std::vector<int32_t> gq(nq), g2(nq), g1(nq);
+    int m = 0, st;
+    std::unique_lock<std::mutex> lock = lock_context();
+    orbamd_ctx* c = ctx();
+    {
+        py::gil_scoped_release nogil;
+        st = orbamd_knn2_ratio(c, q.data(), nq, t.data(), nt, idx.mutable_data(), dist.mutable_data(), gq.data(),
+                               g2.data(), g1.data(), &m);
+    }
+    if (st == ORBAMD_E_BADARG && m == -1)
+        throw py::value_error("not enough values to unpack (expected 2)");  // as views.py:167 would
+    check(st, "match_ratio");
+    auto head = [m](const std::vector<int32_t>& a) {
+        py::array_t<int32_t> r(Shape{m});
+        std::copy(a.data(), a.data() + m, r.mutable_data());
+        return r;
+    };
+    return py::make_tuple(idx, dist, head(gq), head(g2), head(g1));
+}
+
 py::tuple ratio_filter(const py::array_t<int32_t, py::array::c_style | py::array::forcecast>& idx,
                        const py::array_t<int32_t, py::array::c_style | py::array::forcecast>& dist)
 {
@@ -239,6 +268,8 @@ PYBIND11_MODULE(orb_project, m)
           "Hamming 2-nearest neighbours of each row of d1 in d2: (idx int32 [N,2], dist int32 [N,2])");
     m.def("ratio_filter", &ratio_filter, py::arg("idx"), py::arg("dist"),
           "Lowe ratio 0.75 filter: (queryIdx, second trainIdx, first trainIdx) of the kept rows");
+    m.def("match_ratio", &match_ratio, py::arg("d1"), py::arg("d2"),
+          "knn_match2 + ratio_filter in one call: (idx, dist, queryIdx, second trainIdx, first trainIdx)");
     m.def("profile", &profile, py::arg("enable"),
           "Switch per-kernel / host-phase timing of this module's calls on or off (and clear the totals)");
     m.def("profile_read", &profile_read,

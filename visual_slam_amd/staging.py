@@ -76,18 +76,30 @@ class HostFrameStager:
         return StagedChunk(first=first, frames=frames, features=new, matches=self.match[b].view(0, frames))
 
     def run(self, frames_iter):
-        """frames_iter yields uint8 arrays [H, W] (or [H, W, 3] when bgr).  Yields a StagedChunk per
-        `chunk` frames (the last one may be shorter), one chunk behind the uploads."""
+        """frames_iter yields uint8 arrays [H, W] (or [H, W, 3] when bgr) -- or is a frame source with
+        read_into(array) -> bool (visual_slam_amd.frames.FrameFile), which then reads every frame straight
+        into the pinned host chunk, without an intermediate copy.  Yields a StagedChunk per `chunk` frames
+        (the last one may be shorter), one chunk behind the uploads."""
         k, fill, first = 0, 0, 0
         pending = None          # (k, first, frames) uploaded but not processed
         for f in self.feat:
             f.counts[0].zero_()  # a new stream has no previous frame
-        for fr in frames_iter:
+        read_into = getattr(frames_iter, "read_into", None)
+        it = None if read_into else iter(frames_iter)
+        while True:
             b = k & 1
             if fill == 0:
                 # the pinned chunk is free once its previous upload has finished
                 self.copied[b].synchronize() if k >= 2 else None
-            self.host[b][fill].copy_(torch.from_numpy(np.ascontiguousarray(fr)))
+            if read_into:
+                if not read_into(self.host[b][fill].numpy()):
+                    break
+            else:
+                try:
+                    fr = next(it)
+                except StopIteration:
+                    break
+                self.host[b][fill].copy_(torch.from_numpy(np.ascontiguousarray(fr)))
             fill += 1
             if fill == self.chunk:
                 self._upload(k, fill)
