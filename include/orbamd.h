@@ -98,6 +98,25 @@ int orbamd_ctx_set_matcher(orbamd_ctx* ctx, int matcher);
  * descriptors are computed as always. */
 int orbamd_ctx_set_detector(orbamd_ctx* ctx, int threshold, int arc, int wrap, int nms);
 
+/* Parity audit, off by default; no counterpart in the reference.  The reference narrows doubles that come out
+ * of libm calls to float: the angle atan2(m01, m10) * (180 / pi) (src/orb.cpp:127-129) and every rotated sample
+ * coordinate x * cos - y * sin (src/orb.cpp:195-199).  The device's libm is not glibc; a difference in the last
+ * bits of such a double changes the float only if the double lies next to the midpoint of two neighbouring
+ * floats.  With the audit on, the orientation / descriptor kernels count exactly those cases, per frame:
+ *   [0] keypoints whose angle (before narrowing) is within 4 units in the last place of such a midpoint
+ *   [1] sample coordinates (before narrowing) within 4 units in the last place of such a midpoint
+ *   [2] those of [1] for which the two candidate floats, added to the keypoint's coordinate, also round to
+ *       different pixels (src/orb.cpp:202-206) -- only these could change a descriptor bit
+ *   [3] reserved (0)
+ * Expected values are about 1.5e-8 per keypoint / per coordinate for [0] / [1] and practically never for [2];
+ * a frame with a non-zero [0] or [2] is one to re-check on the host if bit-exactness with a glibc build is
+ * required.  The audited kernels issue about a quarter more instructions; results are unchanged.
+ * orbamd_ctx_audit_read copies the counters of the LAST orient / describe / extract call (batch or single
+ * frame; `frames` <= the frames of that call) to host memory, after waiting for the stream:
+ * out = int32 [frames][4].  ORBAMD_E_STATE when the audit is off or no audited call has run. */
+int orbamd_ctx_set_audit(orbamd_ctx* ctx, int on);
+int orbamd_ctx_audit_read(orbamd_ctx* ctx, int32_t* out, int frames);
+
 /* Per-kernel timing: when enabled, every kernel launch is bracketed by HIP events on the
  * context's stream.  orbamd_ctx_timing_read() drains the stream and returns, for kernel kind k
  * (ORBAMD_K_*), the summed milliseconds and launch count since the last reset. */

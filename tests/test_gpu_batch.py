@@ -305,6 +305,27 @@ def test_frame_file_through_the_stager_equals_the_in_memory_path(eng, tmp_path, 
         assert seen == F and src.index == F
 
 
+def test_parity_audit_of_a_batch_changes_nothing_and_reports_per_frame(eng):
+    import torch
+    H, W, F = 240, 320, 12
+    gray = torch.from_numpy(np.stack([synth.synth_frame(H, W, 900 + f, cell=12) for f in range(F)])).to(eng.device)
+    plain = eng.extract_batch(gray)
+    eng.set_audit(True)
+    try:
+        audited = eng.extract_batch(gray)
+        a = eng.audit_read(F)
+    finally:
+        eng.set_audit(False)
+    eng.sync()
+    assert a.shape == (F, 4) and a.min() >= 0 and int(a[:, 2].max()) == 0 and int(a[:, 3].max()) == 0
+    # a handful of keypoints per frame: about 1.5e-8 expected per keypoint and per coordinate
+    assert int(a[:, 0].sum()) <= 2 and int(a[:, 1].sum()) <= 8
+    assert torch.equal(plain.counts, audited.counts)
+    for f in range(F):
+        for x, y in zip(plain.frame(f), audited.frame(f)):
+            assert np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+
+
 def test_extract_batch_capacity_overflow_keeps_first_rows(eng):
     import torch
     from visual_slam_amd.engine import OrbEngine

@@ -1,4 +1,6 @@
 """GPU parity: liborbamd.so (through its C ABI) against the CPU restatement, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -237,6 +239,53 @@ def test_knn2_ratio_is_knn2_then_ratio_filter(gctx, matcher):
         gctx.knn2_ratio(q[:10], t[:1])
     idx, dist, gq, g2, g1 = gctx.knn2_ratio(q[:0], t)
     assert idx.shape == (0, 2) and len(gq) == 0
+
+
+def test_parity_audit_counts_forced_midpoint_coordinates(gctx):
+    """At 265.8927001953125 degrees four rotated sample coordinates (two x and two y values among the 512 pattern
+    points) come out as +-0x1.feaf5cfffffffp+2: one unit in the last place below the midpoint of two floats, where a libm that
+    differs in the last bit would narrow to the other float.  Found by a search over random angles; checked here
+    with the host's libm first.  The audit must count them, call them harmless (no pixel changes), and leave
+    the descriptors exactly as they are without it."""
+    import math
+    import struct
+    from visual_slam_amd import _lib
+    ang = np.float32(265.8927001953125)
+    rad = float(ang) * (3.1415926535897932384626433832795 / 180.0)
+    c, s = math.cos(rad), math.sin(rad)
+    pairs = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "orb_pattern_pairs.txt"),
+                       dtype=np.int64).reshape(-1, 4)
+    near = 0
+    for x1, y1, x2, y2 in pairs:
+        for px, py in ((x1, y1), (x2, y2)):
+            for v in (px * c - py * s, px * s + py * c):
+                lo = struct.unpack("<Q", struct.pack("<d", v))[0] & 0x1FFFFFFF
+                near += abs(lo - 0x10000000) <= 1
+    assert near >= 4
+    img = make_test_image(120, 160, 21)
+    xy = np.array([[70, 60], [40, 45], [5, 60]], np.int32)          # the last one gets no descriptor
+    angles = np.array([ang, 33.25, 10.0], np.float32)
+    want = oracle.c.describe(img, xy, angles)
+    plain = gctx.describe(img, xy, angles)
+    with pytest.raises(_lib.OrbAmdError):
+        gctx.audit_read(1)                                         # audit off: nothing to read
+    gctx.set_audit(True)
+    try:
+        audited = gctx.describe(img, xy, angles)
+        a = gctx.audit_read(1)
+        assert a[0, 1] >= near and a[0, 2] == 0 and a[0, 0] == 0 and a[0, 3] == 0
+        for got in (plain, audited):
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # the orientation kernel and the frame-batch path carry the audit too: results unchanged, counters readable
+        assert np.array_equal(gctx.orient(img, xy).view(np.uint32), oracle.c.orient(img, xy).view(np.uint32))
+        assert gctx.audit_read(1).shape == (1, 4)
+        big = make_test_image(128, 256, 22)                        # rows of whole 16-byte units: the tile kernel
+        assert_extract_equal(gctx.extract_gray(big), oracle.c.extract_gray(big))
+        a = gctx.audit_read(1)
+        assert a.min() >= 0 and a[0, 2] == 0
+    finally:
+        gctx.set_audit(False)
+    assert_extract_equal(gctx.extract_gray(big), oracle.c.extract_gray(big))
 
 
 def test_fetch_after_a_matcher_call_still_returns_the_last_extract(gctx):

@@ -39,6 +39,8 @@ SIGNATURES = {
     "orbamd_last_error": (ctypes.c_char_p, [_c_ctx]),
     "orbamd_ctx_set_matcher": (_int, [_c_ctx, _int]),
     "orbamd_ctx_set_detector": (_int, [_c_ctx, _int, _int, _int, _int]),
+    "orbamd_ctx_set_audit": (_int, [_c_ctx, _int]),
+    "orbamd_ctx_audit_read": (_int, [_c_ctx, _vp, _int]),
     "orbamd_ctx_timing_enable": (_int, [_c_ctx, _int]),
     "orbamd_ctx_timing_reset": (_int, [_c_ctx]),
     "orbamd_ctx_timing_read": (_int, [_c_ctx, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
@@ -178,6 +180,17 @@ class Context:
         """Detector extension (off by default = the reference's detector): see include/orbamd.h."""
         self._chk(lib().orbamd_ctx_set_detector(self._h, int(threshold), int(arc), 1 if wrap else 0,
                                                 1 if nms else 0), "set_detector")
+
+    def set_audit(self, on=True):
+        """Parity audit (see include/orbamd.h): count narrowings that a different libm could round the other way."""
+        self._chk(lib().orbamd_ctx_set_audit(self._h, 1 if on else 0), "set_audit")
+
+    def audit_read(self, frames=1):
+        """-> int32 [frames, 4]: (angles, coordinates near a float midpoint, decisive coordinates, 0) per frame of
+        the last orient / describe / extract call."""
+        out = np.zeros((frames, 4), np.int32)
+        self._chk(lib().orbamd_ctx_audit_read(self._h, _np_ptr(out), int(frames)), "audit_read")
+        return out
 
     def timing_enable(self, on=True):
         self._chk(lib().orbamd_ctx_timing_enable(self._h, 1 if on else 0), "timing_enable")

@@ -50,7 +50,9 @@ struct orbamd_ctx {
 
     // work buffers
     DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle, score;
-    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount;
+    DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount, risk;
+    bool audit = false;       // parity audit on: the describe kernels count near-midpoint narrowings into `risk`
+    int risk_frames = 0;      // frames the last audited call covered
     int matcher = ORBAMD_MATCHER_MATRIX;
     // detector parameters; the defaults are the reference's (src/orb.cpp:39, :70-96) and select its kernel
     int det_thr = 20, det_arc = 12, det_wrap = 0, det_nms = 0;
@@ -403,6 +405,19 @@ int run_knn2(orbamd_ctx* c, Knn2Args& a, void* scratch_mem = nullptr, size_t scr
     return ORBAMD_OK;
 }
 
+// Parity audit: zeroed counters for `frames` frames when the audit is on, NULL otherwise.
+int audit_buffer(orbamd_ctx* c, int frames, int32_t** out)
+{
+    *out = nullptr;
+    c->risk_frames = 0;
+    if (!c->audit) return ORBAMD_OK;
+    CHK(ensure(c, c->risk, (size_t)frames * 4 * sizeof(int32_t)));
+    HIPCHK(c, hipMemsetAsync(c->risk.p, 0, (size_t)frames * 4 * sizeof(int32_t), c->stream));
+    c->risk_frames = frames;
+    *out = (int32_t*)c->risk.p;
+    return ORBAMD_OK;
+}
+
 // Orientation + descriptors for the scan-ordered lists in c->kpxy / c->kpslot (as run_emit leaves them).
 // Frames made of whole aligned 16-byte units are described tile by tile from LDS, the others keypoint by
 // keypoint; the results are the same.
@@ -411,14 +426,16 @@ int run_describe(orbamd_ctx* c, const FrameSet& fs, const int32_t* d_counts, int
 {
     static const bool per_keypoint = getenv("ORBAMD_DESCRIBE_PER_KEYPOINT") != nullptr;   // (for A/B timing)
     const bool tiles = !per_keypoint && (fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0;
+    int32_t* risk = nullptr;
+    CHK(audit_buffer(c, fs.frames, &risk));
     {
         Timed t(c, ORBAMD_K_DESCRIBE);
         if (tiles)
             launch_describe_tiles(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap,
-                                  (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, c->stream);
+                                  (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, risk, c->stream);
         else
             launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap, nullptr,
-                                   d_kp7, nullptr, d_desc, d_valid_idx, c->stream);
+                                   d_kp7, nullptr, d_desc, d_valid_idx, risk, c->stream);
     }
     return post_launch(c, tiles ? "describe_tile_kernel" : "orient_describe_kernel");
 }
@@ -563,6 +580,24 @@ int orbamd_ctx_set_detector(orbamd_ctx* c, int threshold, int arc, int wrap, int
     return ORBAMD_OK;
 }
 
+int orbamd_ctx_set_audit(orbamd_ctx* c, int on)
+{
+    if (!c) return ORBAMD_E_BADARG;
+    c->audit = on != 0;
+    c->risk_frames = 0;
+    return ORBAMD_OK;
+}
+
+int orbamd_ctx_audit_read(orbamd_ctx* c, int32_t* out, int frames)
+{
+    CHK(enter(c));
+    if (!out || frames <= 0) return ORBAMD_E_BADARG;
+    if (!c->audit || c->risk_frames <= 0 || frames > c->risk_frames) return ORBAMD_E_STATE;
+    HIPCHK(c, hipMemcpyAsync(out, c->risk.p, (size_t)frames * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return ORBAMD_OK;
+}
+
 int orbamd_ctx_destroy(orbamd_ctx* c)
 {
     if (!c) return ORBAMD_E_BADARG;
@@ -570,7 +605,7 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
                       &c->kp7, &c->desc, &c->vidx, &c->angle, &c->score, &c->q, &c->t, &c->idx, &c->dist, &c->good,
-                      &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount};
+                      &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount, &c->risk};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& t : c->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -750,11 +785,13 @@ int orbamd_orient(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int32_
     c->h_counts[1] = 0;
     HIPCHK(c, hipMemcpyAsync(c->counts.p, c->h_counts, 8, hipMemcpyHostToDevice, c->stream));
     FrameSet fs{(const uint8_t*)c->gray.p, 1, H, W};
+    int32_t* risk = nullptr;
+    CHK(audit_buffer(c, 1, &risk));
     {
         Timed t(c, ORBAMD_K_DESCRIBE);
         launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
                                (const int32_t*)c->counts.p, n, nullptr, nullptr, (float*)c->angle.p, nullptr,
-                               nullptr, c->stream);
+                               nullptr, risk, c->stream);
     }
     CHK(post_launch(c, "orient_describe_kernel"));
     HIPCHK(c, hipMemcpyAsync(angle_out, c->angle.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -780,11 +817,13 @@ int orbamd_describe(orbamd_ctx* c, const uint8_t* gray, int H, int W, const int3
     launch_slots((const int2*)c->kpxy.p, n, H, W, (int32_t*)c->kpslot.p, (int32_t*)c->counts.p, c->stream);
     CHK(post_launch(c, "slots_kernel"));
     FrameSet fs{(const uint8_t*)c->gray.p, 1, H, W};
+    int32_t* risk = nullptr;
+    CHK(audit_buffer(c, 1, &risk));
     {
         Timed t(c, ORBAMD_K_DESCRIBE);
         launch_orient_describe(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p,
                                (const int32_t*)c->counts.p, n, (const float*)c->angle.p, nullptr, nullptr,
-                               (uint8_t*)c->desc.p, (int32_t*)c->vidx.p, c->stream);
+                               (uint8_t*)c->desc.p, (int32_t*)c->vidx.p, risk, c->stream);
     }
     CHK(post_launch(c, "orient_describe_kernel"));
     CHK(read_counts(c, (const int32_t*)c->counts.p, 2));

@@ -1069,11 +1069,35 @@ void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_
 // ---------------------------------------------------------------------------------------------
 constexpr double ORB_PI = 3.1415926535897932384626433832795;
 
-__device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01)
+// Parity audit.  The reference narrows doubles that come out of libm calls (atan2; products with cos / sin)
+// to float (src/orb.cpp:129, :195-199).  A libm whose results differ in the last bits gives the same float
+// unless the double sits next to the midpoint of two neighbouring floats.  near_float_midpoint: the 29 bits
+// the narrowing drops are within 4 of that midpoint pattern.
+__device__ __forceinline__ bool near_float_midpoint(double v)
 {
+    const uint32_t lo = (uint32_t)__double2loint(v);
+    return (((lo + 4u) - 0x10000000u) & 0x1FFFFFFFu) <= 8u;
+}
+
+// One rotated sample coordinate before narrowing, and the float centre it is added to.  Bit 0: near a
+// float midpoint; bit 1: the two candidate floats would also round to different pixels.
+__device__ __forceinline__ uint32_t audit_coord(double v, float centre)
+{
+    if (!near_float_midpoint(v)) return 0u;
+    const float f = (float)v;
+    if (f == 0.0f) return 1u;
+    const float g = __uint_as_float(__float_as_uint(f) + (((double)f < v) == (f >= 0.0f) ? 1u : 0xFFFFFFFFu));
+    return __float2int_rn(centre + f) != __float2int_rn(centre + g) ? 3u : 1u;
+}
+
+__device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01, bool* near_midpoint = nullptr)
+{
+    if (near_midpoint) *near_midpoint = false;
     if (m00 == 0) return 0.0f;
     double a = atan2((double)m01, (double)m10);
-    float ang = (float)(a * (180.0 / ORB_PI));
+    const double deg = a * (180.0 / ORB_PI);
+    if (near_midpoint) *near_midpoint = near_float_midpoint(deg);
+    float ang = (float)deg;
     if (ang < 0) ang = (float)((double)ang + 360.0);
     return ang;
 }
@@ -1257,12 +1281,12 @@ constexpr uint32_t RND_MAGIC_BITS = 0x4B400000u;
 
 // At most 5 waves per SIMD: with more, the windows and patches of the resident waves no longer fit
 // the vector L1 cache and the kernel runs 10 - 15 % slower on MI355X.
-template <int KPW>
+template <int KPW, bool AUDIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void orient_describe_kernel(
     const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
     const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
     const float* __restrict__ angle_in, float* __restrict__ kp7, float* __restrict__ angle_out,
-    uint8_t* __restrict__ desc, int32_t* __restrict__ valid_idx, int dwords, int nbf)
+    uint8_t* __restrict__ desc, int32_t* __restrict__ valid_idx, int dwords, int nbf, int32_t* __restrict__ risk)
 {
     // 1-D grid of frames * nbf workgroups, nbf (workgroups per frame) odd: see xcd_contiguous_item().
     const uint32_t item = xcd_contiguous_item();
@@ -1357,7 +1381,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
         }
         // ---- phase B (first half): one atan2 per lane ----
-        angle = angle_from_moments(m00, m10, m01);
+        if (AUDIT) {
+            bool near;
+            angle = angle_from_moments(m00, m10, m01, &near);
+            if (mine && near) atomicAdd(&risk[4 * f], 1);
+        } else {
+            angle = angle_from_moments(m00, m10, m01);
+        }
     }
     if (mine) {
         if (angle_out) angle_out[k0 + kidx] = angle;
@@ -1380,6 +1410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
     // ---- phase C: descriptors, one keypoint at a time ----
     unsigned long long todo = __ballot(slot >= 0);
+    int aud_mid = 0, aud_dec = 0;            // parity audit: this lane's coordinates near a float midpoint / decisive
     if (dwords) {
         // The 512 samples of a keypoint fall in the 43x43 square around it (|rotated offset| <=
         // 21.3).  Scattered byte gathers from global memory cost one cache line per lane; instead the
@@ -1480,19 +1511,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 asm volatile("" : "+v"(cx), "+v"(cy), "+v"(mx), "+v"(my));   // vector copies: scalar operands halve the add rate
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x1r, y1r, x2r, y2r;
+                    double vx1, vy1, vx2, vy2;
                     if (r < ROT_TABLE_ROUNDS) {
                         const double2 e1x = *t1x[r], e1y = *t1y[r], e2x = *t2x[r], e2y = *t2y[r];
-                        x1r = (float)(e1x.x - e1y.y);     // px1 * c - py1 * s
-                        y1r = (float)(e1x.y + e1y.x);     // px1 * s + py1 * c
-                        x2r = (float)(e2x.x - e2y.y);
-                        y2r = (float)(e2x.y + e2y.x);
+                        vx1 = e1x.x - e1y.y;     // px1 * c - py1 * s
+                        vy1 = e1x.y + e1y.x;     // px1 * s + py1 * c
+                        vx2 = e2x.x - e2y.y;
+                        vy2 = e2x.y + e2y.x;
                     } else {
-                        x1r = (float)(dpx1[r] * cj - dpy1[r] * sn);
-                        y1r = (float)(dpx1[r] * sn + dpy1[r] * cj);
-                        x2r = (float)(dpx2[r] * cj - dpy2[r] * sn);
-                        y2r = (float)(dpx2[r] * sn + dpy2[r] * cj);
+                        vx1 = dpx1[r] * cj - dpy1[r] * sn;
+                        vy1 = dpx1[r] * sn + dpy1[r] * cj;
+                        vx2 = dpx2[r] * cj - dpy2[r] * sn;
+                        vy2 = dpx2[r] * sn + dpy2[r] * cj;
                     }
+                    if (AUDIT) {
+                        const uint32_t a4[4] = {audit_coord(vx1, cx), audit_coord(vy1, cy), audit_coord(vx2, cx),
+                                                audit_coord(vy2, cy)};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { aud_mid += a4[k] & 1u; aud_dec += a4[k] >> 1; }
+                    }
+                    const float x1r = (float)vx1, y1r = (float)vy1, x2r = (float)vx2, y2r = (float)vy2;
                     const uint32_t ax = __float_as_uint((cx + x1r) + mx);
                     const uint32_t ay = __float_as_uint((cy + y1r) + my);
                     const uint32_t bx = __float_as_uint((cx + x2r) + mx);
@@ -1542,10 +1580,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             unsigned long long bal[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x1r = (float)(px1[r] * cj - py1[r] * sn);
-                const float y1r = (float)(px1[r] * sn + py1[r] * cj);
-                const float x2r = (float)(px2[r] * cj - py2[r] * sn);
-                const float y2r = (float)(px2[r] * sn + py2[r] * cj);
+                const double vx1 = px1[r] * cj - py1[r] * sn, vy1 = px1[r] * sn + py1[r] * cj;
+                const double vx2 = px2[r] * cj - py2[r] * sn, vy2 = px2[r] * sn + py2[r] * cj;
+                if (AUDIT && finite) {
+                    const uint32_t a4[4] = {audit_coord(vx1, cx), audit_coord(vy1, cy), audit_coord(vx2, cx),
+                                            audit_coord(vy2, cy)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { aud_mid += a4[k] & 1u; aud_dec += a4[k] >> 1; }
+                }
+                const float x1r = (float)vx1, y1r = (float)vy1, x2r = (float)vx2, y2r = (float)vy2;
                 const int ax = __float2int_rn(cx + x1r), ay = __float2int_rn(cy + y1r);
                 const int bx = __float2int_rn(cx + x2r), by = __float2int_rn(cy + y2r);
                 int v1 = 0, v2 = 0;
@@ -1557,6 +1600,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const unsigned long long w = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
                 reinterpret_cast<unsigned long long*>(desc + ((size_t)f * cap + sj) * 32)[lane] = w;
             }
+        }
+    }
+    if (AUDIT) {
+        const int tm = wave_total(aud_mid), td = wave_total(aud_dec);
+        if (lane == 0) {
+            if (tm) atomicAdd(&risk[4 * f + 1], tm);
+            if (td) atomicAdd(&risk[4 * f + 2], td);
         }
     }
 }
@@ -1600,11 +1650,12 @@ struct DescribeTileLds {
 static_assert((256 * DT_STEPS - DT_UNITS) * 16 <= (int)sizeof(double2) * DT_BATCH, "load overrun stays inside cs");
 static_assert(sizeof(DescribeTileLds) <= 40960, "four workgroups per CU");
 
+template <bool AUDIT>
 __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
     const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
     const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
     const int2* __restrict__ rowoff, float* __restrict__ kp7, uint8_t* __restrict__ desc,
-    int32_t* __restrict__ valid_idx, int ntc, int nbands)
+    int32_t* __restrict__ valid_idx, int ntc, int nbands, int32_t* __restrict__ risk)
 {
     __shared__ __attribute__((aligned(16))) DescribeTileLds L;
     uint32_t* const tile32 = L.tile32;
@@ -1671,6 +1722,7 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int aud_mid = 0, aud_dec = 0;            // parity audit: this lane's coordinates near a float midpoint / decisive
 
     for (int s0 = k0; s0 < k1; s0 += DT_SEG) {
         // ---- gather: entries of the band's range whose column falls into this tile ----
@@ -1745,7 +1797,14 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                 // ---- one keypoint per thread: angle, keypoint row, cos / sin ----
                 if (t < nb) {
                     const int* m = reinterpret_cast<const int*>(&cs[t]);
-                    const float angle = angle_from_moments(m[0], m[1], m[2]);
+                    float angle;
+                    if (AUDIT) {
+                        bool near;
+                        angle = angle_from_moments(m[0], m[1], m[2], &near);
+                        if (near) atomicAdd(&risk[4 * f], 1);
+                    } else {
+                        angle = angle_from_moments(m[0], m[1], m[2]);
+                    }
                     const uint32_t pxy = lst_xy[bb + t];
                     const int i = lst_idx[bb + t];
                     float* row = kp7 + (kf + i) * 7;
@@ -1776,10 +1835,15 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
                     uint32_t i1[4], i2[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float x1r = (float)(dpx1[r] * cj - dpy1[r] * sn);
-                        const float y1r = (float)(dpx1[r] * sn + dpy1[r] * cj);
-                        const float x2r = (float)(dpx2[r] * cj - dpy2[r] * sn);
-                        const float y2r = (float)(dpx2[r] * sn + dpy2[r] * cj);
+                        const double vx1 = dpx1[r] * cj - dpy1[r] * sn, vy1 = dpx1[r] * sn + dpy1[r] * cj;
+                        const double vx2 = dpx2[r] * cj - dpy2[r] * sn, vy2 = dpx2[r] * sn + dpy2[r] * cj;
+                        if (AUDIT) {
+                            const uint32_t a4[4] = {audit_coord(vx1, cx), audit_coord(vy1, cy), audit_coord(vx2, cx),
+                                                    audit_coord(vy2, cy)};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { aud_mid += a4[k] & 1u; aud_dec += a4[k] >> 1; }
+                        }
+                        const float x1r = (float)vx1, y1r = (float)vy1, x2r = (float)vx2, y2r = (float)vy2;
                         const uint32_t ax = __float_as_uint((cx + x1r) + mx);
                         const uint32_t ay = __float_as_uint((cy + y1r) + my);
                         const uint32_t bx = __float_as_uint((cx + x2r) + mx);
@@ -1804,35 +1868,56 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
         if (t == 0) L.lst_count = 0;
         __syncthreads();
     }
+    if (AUDIT) {
+        const int tm = wave_total(aud_mid), td = wave_total(aud_dec);
+        if (lane == 0) {
+            if (tm) atomicAdd(&risk[4 * f + 1], tm);
+            if (td) atomicAdd(&risk[4 * f + 2], td);
+        }
+    }
 }
 
 void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts,
-                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
+                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, int32_t* risk,
+                           hipStream_t s)
 {
     const int ntc = (fs.W + DT_W - 1) / DT_W, nbands = (fs.H + DT_H - 1) / DT_H;
-    static const unsigned pad = lds_pad_from_env("ORBAMD_PAD_LDS_DESCRIBE", (const void*)describe_tile_kernel);
-    hipLaunchKernelGGL(describe_tile_kernel, dim3((unsigned)((size_t)ntc * nbands * fs.frames)), dim3(256), pad, s,
-                       fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, rowoff, kp7, desc, valid_idx, ntc, nbands);
+    static const unsigned pad = lds_pad_from_env("ORBAMD_PAD_LDS_DESCRIBE", (const void*)describe_tile_kernel<false>);
+    const dim3 grid((unsigned)((size_t)ntc * nbands * fs.frames));
+    if (risk)
+        hipLaunchKernelGGL(describe_tile_kernel<true>, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot, counts,
+                           cap, rowoff, kp7, desc, valid_idx, ntc, nbands, risk);
+    else
+        hipLaunchKernelGGL(describe_tile_kernel<false>, grid, dim3(256), pad, s, fs.gray, fs.H, fs.W, kpxy, kpslot,
+                           counts, cap, rowoff, kp7, desc, valid_idx, ntc, nbands, risk);
+}
+
+template <int KPW>
+static void launch_orient_describe_kpw(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
+                                       const int32_t* counts, int cap, const float* angle_in, float* kp7,
+                                       float* angle_out, uint8_t* desc, int32_t* valid_idx, int32_t* risk, hipStream_t s)
+{
+    const int dwords = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
+    const int nbf = ((cap + 4 * KPW - 1) / (4 * KPW)) | 1;
+    const dim3 grid((unsigned)((size_t)nbf * fs.frames));
+    if (risk)
+        hipLaunchKernelGGL((orient_describe_kernel<KPW, true>), grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot,
+                           counts, cap, angle_in, kp7, angle_out, desc, valid_idx, dwords, nbf, risk);
+    else
+        hipLaunchKernelGGL((orient_describe_kernel<KPW, false>), grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot,
+                           counts, cap, angle_in, kp7, angle_out, desc, valid_idx, dwords, nbf, risk);
 }
 
 void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
                             const int32_t* counts, int cap, const float* angle_in, float* kp7,
-                            float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s)
+                            float* angle_out, uint8_t* desc, int32_t* valid_idx, int32_t* risk, hipStream_t s)
 {
-    const int dwords = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
     // Big launches: 64 keypoints per wave (library calls amortised 64-fold).  Small launches
     // (single frames): 16 per wave, so that a few thousand keypoints still spread over the chip.
-    if ((long)fs.frames * cap >= 64L * 8192) {
-        const int nbf = ((cap + 4 * 64 - 1) / (4 * 64)) | 1;
-        hipLaunchKernelGGL(orient_describe_kernel<64>, dim3((unsigned)((size_t)nbf * fs.frames)), dim3(256), 0, s,
-                           fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc,
-                           valid_idx, dwords, nbf);
-    } else {
-        const int nbf = ((cap + 4 * 16 - 1) / (4 * 16)) | 1;
-        hipLaunchKernelGGL(orient_describe_kernel<16>, dim3((unsigned)((size_t)nbf * fs.frames)), dim3(256), 0, s,
-                           fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc,
-                           valid_idx, dwords, nbf);
-    }
+    if ((long)fs.frames * cap >= 64L * 8192)
+        launch_orient_describe_kpw<64>(fs, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc, valid_idx, risk, s);
+    else
+        launch_orient_describe_kpw<16>(fs, kpxy, kpslot, counts, cap, angle_in, kp7, angle_out, desc, valid_idx, risk, s);
 }
 
 // ---------------------------------------------------------------------------------------------

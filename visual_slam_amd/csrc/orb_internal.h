@@ -58,15 +58,20 @@ void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, c
 //   kp7     [frames][cap][7] or NULL;  angle_out [frames][cap] or NULL
 //   angle_in: when non-NULL the orientation step is skipped and these angles are used
 //   desc    [frames][cap][32] or NULL (then no descriptors are computed)
+//   risk    [frames][4] int32 or NULL: parity-audit counters that the kernel ADDS to (the caller zeroes them):
+//           [0] keypoints whose angle, [1] sample coordinates whose value is within 4 units in the last place
+//           of the midpoint of two floats before the reference narrows it to float, [2] those of [1] whose two
+//           candidate floats also round to different pixels.  NULL runs the kernels without the audit code.
 void launch_orient_describe(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot,
                             const int32_t* counts, int cap, const float* angle_in, float* kp7,
-                            float* angle_out, uint8_t* desc, int32_t* valid_idx, hipStream_t s);
+                            float* angle_out, uint8_t* desc, int32_t* valid_idx, int32_t* risk, hipStream_t s);
 
 // The same results for whole frames whose keypoint lists are in scan order (as launch_emit leaves them),
 // computed tile by tile from LDS: rowoff [frames][H] as written by launch_rowscan.  Needs rows of whole
 // aligned 16-byte units (W % 16 == 0, 16-byte-aligned frames); kp7 and desc must not be NULL.
 void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts,
-                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, hipStream_t s);
+                           int cap, const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, int32_t* risk,
+                           hipStream_t s);
 
 struct Knn2Args {
     const uint8_t* qdesc;     // query descriptor base

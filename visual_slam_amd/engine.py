@@ -93,6 +93,14 @@ class OrbEngine:
         if self._match_ctx is not None:
             self._match_ctx.set_matcher(matcher)
 
+    def set_audit(self, on=True):
+        """Parity audit of the following extract_batch calls (see orbamd_ctx_set_audit in include/orbamd.h)."""
+        self.ctx.set_audit(on)
+
+    def audit_read(self, frames):
+        """int32 [frames, 4] numpy array for the last extract_batch call (synchronises)."""
+        return self.ctx.audit_read(frames)
+
     # -- inputs ---------------------------------------------------------------------------------
     def synth_frames(self, frames, H, W, first_frame=0, seed=synth.DEFAULT_SEED, cell=20, density=0.386):
         out = torch.empty((frames, H, W), dtype=torch.uint8, device=self.device)
