@@ -1108,6 +1108,33 @@ int orbamd_extract_batch_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, i
     return run_describe(c, fs, d_counts, cap, d_kp7, d_desc, d_valid_idx);
 }
 
+// MEASUREMENT entry point (not part of include/orbamd.h): orbamd_extract_batch_dev for one batch whose
+// orientation + descriptor kernel is fused with orbamd_knn2_batch_dev over the consecutive pairs of ANOTHER,
+// already extracted batch (d_mdesc, d_mcounts) into one launch with role-specialised workgroups.
+int orbamd_x_describe_match_dev(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, int W, int cap, float* d_kp7,
+                                uint8_t* d_desc, int32_t* d_valid_idx, int32_t* d_counts, const uint8_t* d_mdesc,
+                                const int32_t* d_mcounts, int mframes, int mcap, int32_t* d_idx, int32_t* d_dist,
+                                uint8_t* d_good, int qt)
+{
+    CHK(enter(c));
+    if (!d_gray || !d_kp7 || !d_desc || !d_counts || !d_mdesc || !d_mcounts || !d_idx || !d_dist || frames <= 0 ||
+        frames > 65535 || cap <= 0 || cap > ORBAMD_MAX_CAP || mframes < 2 || mcap <= 0 || mcap > ORBAMD_MAX_TRAIN ||
+        (qt != 2 && qt != 4) || (W & 15) || ((uintptr_t)d_gray & 15) || misaligned16(d_mdesc))
+        return ORBAMD_E_BADARG;
+    CHK(check_image(H, W));
+    c->have_extract = false;
+    CHK(run_detect_counts(c, d_gray, frames, H, W, d_counts));
+    CHK(run_emit(c, d_gray, frames, H, W, cap, d_counts));
+    FrameSet fs{d_gray, frames, H, W};
+    {
+        Timed t(c, ORBAMD_K_DESCRIBE);
+        launch_describe_match(fs, (const int2*)c->kpxy.p, (const int32_t*)c->kpslot.p, d_counts, cap,
+                              (const int2*)c->rowoff.p, d_kp7, d_desc, d_valid_idx, d_mdesc, d_mcounts, mframes, mcap,
+                              d_idx, d_dist, d_good, qt, c->stream);
+    }
+    return post_launch(c, "describe_match_kernel");
+}
+
 int orbamd_knn2_batch_dev(orbamd_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int frames, int cap,
                           const int32_t* d_pairs, int npairs, int32_t* d_idx, int32_t* d_dist, uint8_t* d_good)
 {

@@ -1650,20 +1650,19 @@ struct DescribeTileLds {
 static_assert((256 * DT_STEPS - DT_UNITS) * 16 <= (int)sizeof(double2) * DT_BATCH, "load overrun stays inside cs");
 static_assert(sizeof(DescribeTileLds) <= 40960, "four workgroups per CU");
 
+// One workgroup's tile: `item` numbers the (frame, band, tile column) triples, tile column fastest.
 template <bool AUDIT>
-__global__ __launch_bounds__(256, 4) void describe_tile_kernel(
-    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+__device__ __forceinline__ void describe_tile_body(
+    DescribeTileLds& L, uint32_t item, const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
     const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
     const int2* __restrict__ rowoff, float* __restrict__ kp7, uint8_t* __restrict__ desc,
     int32_t* __restrict__ valid_idx, int ntc, int nbands, int32_t* __restrict__ risk)
 {
-    __shared__ __attribute__((aligned(16))) DescribeTileLds L;
     uint32_t* const tile32 = L.tile32;
     uint32_t* const lst_xy = L.lst_xy;
     int32_t* const lst_idx = L.lst_idx;
     double2* const cs = L.cs;
 
-    const uint32_t item = xcd_contiguous_item();
     const int tc = (int)(item % (uint32_t)ntc);
     const uint32_t rest = item / (uint32_t)ntc;
     const int band = (int)(rest % (uint32_t)nbands);
@@ -1875,6 +1874,18 @@ __global__ __launch_bounds__(256, 4) void describe_tile_kernel(
             if (td) atomicAdd(&risk[4 * f + 2], td);
         }
     }
+}
+
+template <bool AUDIT>
+__global__ __launch_bounds__(256, 4) void describe_tile_kernel(
+    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
+    const int2* __restrict__ rowoff, float* __restrict__ kp7, uint8_t* __restrict__ desc,
+    int32_t* __restrict__ valid_idx, int ntc, int nbands, int32_t* __restrict__ risk)
+{
+    __shared__ __attribute__((aligned(16))) DescribeTileLds L;
+    describe_tile_body<AUDIT>(L, xcd_contiguous_item(), gray, H, W, kpxy, kpslot, counts, cap, rowoff, kp7, desc,
+                              valid_idx, ntc, nbands, risk);
 }
 
 void launch_describe_tiles(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts,
@@ -2406,22 +2417,21 @@ __device__ __forceinline__ void knn2_mfma_wave(uint4 (*stage)[256], const uint32
 // in every instantiation.)
 // Three waves per SIMD (<= 168 registers per lane); the compiler keeps the
 // accumulators in ordinary VGPRs, which the top-2 instructions can read directly.
+// One workgroup's block of queries: `logical` numbers the (pair, train split, query block) triples, query block
+// fastest.
 template <int QTMAX, bool PARTIAL>
-__global__ __launch_bounds__(256, 3) void knn2_mfma_kernel(const uint8_t* __restrict__ qdesc,
-                                                        const uint8_t* __restrict__ tdesc,
-                                                        const int32_t* __restrict__ qcounts,
-                                                        const int32_t* __restrict__ tcounts,
-                                                        const int32_t* __restrict__ pairs, int qframe0,
-                                                        int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
-                                                        int splits, int nbp, uint32_t* __restrict__ partial,
-                                                        int32_t* __restrict__ idx, int32_t* __restrict__ dist,
-                                                        uint8_t* __restrict__ good)
+__device__ __forceinline__ void knn2_mfma_body(uint4 (*stage)[256], uint32_t logical, const uint8_t* __restrict__ qdesc,
+                                               const uint8_t* __restrict__ tdesc,
+                                               const int32_t* __restrict__ qcounts,
+                                               const int32_t* __restrict__ tcounts,
+                                               const int32_t* __restrict__ pairs, int qframe0,
+                                               int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
+                                               int splits, int nbp, uint32_t* __restrict__ partial,
+                                               int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                               uint8_t* __restrict__ good)
 {
-    __shared__ uint4 stage[2 * KNN2_GROUP][256];
-
     int pair, zsplit, qblk;
     {
-        const uint32_t logical = xcd_contiguous_item();
         const uint32_t per_pair = (uint32_t)nbp * (uint32_t)splits;
         pair = (int)(logical / per_pair);
         const uint32_t rem = logical - (uint32_t)pair * per_pair;
@@ -2456,9 +2466,91 @@ __global__ __launch_bounds__(256, 3) void knn2_mfma_kernel(const uint8_t* __rest
     if (nu == QTMAX) ORB_KNN2_WAVE(QTMAX, true);
     else if (nu == 0) ORB_KNN2_WAVE(1, false);
     else if (nu == 1) ORB_KNN2_WAVE(1, true);
-    else if (QTMAX == 4 && nu == 2) ORB_KNN2_WAVE(2, true);
-    else ORB_KNN2_WAVE(3, true);
+    else if constexpr (QTMAX == 4) {
+        if (nu == 2) ORB_KNN2_WAVE(2, true);
+        else ORB_KNN2_WAVE(3, true);
+    }
 #undef ORB_KNN2_WAVE
+}
+
+template <int QTMAX, bool PARTIAL>
+__global__ __launch_bounds__(256, 3) void knn2_mfma_kernel(const uint8_t* __restrict__ qdesc,
+                                                        const uint8_t* __restrict__ tdesc,
+                                                        const int32_t* __restrict__ qcounts,
+                                                        const int32_t* __restrict__ tcounts,
+                                                        const int32_t* __restrict__ pairs, int qframe0,
+                                                        int tframe0, int nframes, int cap, int nq_fixed, int nt_fixed,
+                                                        int splits, int nbp, uint32_t* __restrict__ partial,
+                                                        int32_t* __restrict__ idx, int32_t* __restrict__ dist,
+                                                        uint8_t* __restrict__ good)
+{
+    __shared__ uint4 stage[2 * KNN2_GROUP][256];
+    knn2_mfma_body<QTMAX, PARTIAL>(stage, xcd_contiguous_item(), qdesc, tdesc, qcounts, tcounts, pairs, qframe0, tframe0,
+                                   nframes, cap, nq_fixed, nt_fixed, splits, nbp, partial, idx, dist, good);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MEASUREMENT KERNEL: orientation + descriptors of one frame batch and Hamming top-2 of ANOTHER batch's
+// descriptors in one launch, with role-specialised workgroups, so that workgroups of both kinds are resident on
+// every compute unit at the same time by construction (workgroups are dispatched in index order; groups of 8
+// consecutive indices = one per XCD alternate between the roles at the ratio of the two item counts).  It
+// exists to answer one question with counters: do the vector-bound extraction and the matrix-bound matcher
+// gain from sharing SIMDs?  Same device code as the two kernels above, same results.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t DM_LDS_BYTES = sizeof(DescribeTileLds) > sizeof(uint4) * 2 * KNN2_GROUP * 256
+                                    ? sizeof(DescribeTileLds) : sizeof(uint4) * 2 * KNN2_GROUP * 256;
+
+template <int QTMAX>
+__global__ __launch_bounds__(256, QTMAX == 4 ? 3 : 4) void describe_match_kernel(
+    // describe role
+    const uint8_t* __restrict__ gray, int H, int W, const int2* __restrict__ kpxy,
+    const int32_t* __restrict__ kpslot, const int32_t* __restrict__ counts, int cap,
+    const int2* __restrict__ rowoff, float* __restrict__ kp7, uint8_t* __restrict__ desc,
+    int32_t* __restrict__ valid_idx, int ntc, int nbands, uint32_t n_describe,
+    // matcher role (consecutive pairs of another feature buffer)
+    const uint8_t* __restrict__ mdesc, const int32_t* __restrict__ mcounts, int mframes, int mcap, int nbp,
+    int32_t* __restrict__ idx, int32_t* __restrict__ dist, uint8_t* __restrict__ good, uint32_t n_match,
+    uint32_t every)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[DM_LDS_BYTES];
+    const uint32_t g = blockIdx.x >> 3, x = blockIdx.x & 7u;
+    const uint32_t mgroups = (n_match + 7u) >> 3, dgroups = (n_describe + 7u) >> 3;
+    const bool mrole = (g % every == 0u) && (g / every < mgroups);
+    if (mrole) {
+        const uint32_t item = x * mgroups + g / every;
+        if (item >= n_match) return;
+        knn2_mfma_body<QTMAX, false>(reinterpret_cast<uint4(*)[256]>(lds_raw), item, mdesc, mdesc, mcounts, mcounts,
+                                     nullptr, 0, 0, mframes, mcap, 0, 0, 1, nbp, nullptr, idx, dist, good);
+    } else {
+        uint32_t mbefore = (g + every - 1u) / every;
+        mbefore = mbefore < mgroups ? mbefore : mgroups;
+        const uint32_t item = x * dgroups + (g - mbefore);
+        if (item >= n_describe) return;
+        describe_tile_body<false>(*reinterpret_cast<DescribeTileLds*>(lds_raw), item, gray, H, W, kpxy, kpslot, counts,
+                                  cap, rowoff, kp7, desc, valid_idx, ntc, nbands, nullptr);
+    }
+}
+
+void launch_describe_match(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts, int cap,
+                           const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, const uint8_t* mdesc,
+                           const int32_t* mcounts, int mframes, int mcap, int32_t* idx, int32_t* dist, uint8_t* good,
+                           int qt, hipStream_t s)
+{
+    const int ntc = (fs.W + DT_W - 1) / DT_W, nbands = (fs.H + DT_H - 1) / DT_H;
+    const uint32_t n_describe = (uint32_t)((size_t)ntc * nbands * fs.frames);
+    const int nbp = (mcap + 128 * qt - 1) / (128 * qt);
+    const uint32_t n_match = (uint32_t)((size_t)nbp * (mframes - 1));
+    const uint32_t mgroups = (n_match + 7u) >> 3, dgroups = (n_describe + 7u) >> 3;
+    const uint32_t every = mgroups ? (mgroups + dgroups) / mgroups : 1u;
+    const dim3 grid(8u * (mgroups + dgroups));
+    if (qt == 4)
+        hipLaunchKernelGGL(describe_match_kernel<4>, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap,
+                           rowoff, kp7, desc, valid_idx, ntc, nbands, n_describe, mdesc, mcounts, mframes, mcap, nbp, idx,
+                           dist, good, n_match, every);
+    else
+        hipLaunchKernelGGL(describe_match_kernel<2>, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, kpxy, kpslot, counts, cap,
+                           rowoff, kp7, desc, valid_idx, ntc, nbands, n_describe, mdesc, mcounts, mframes, mcap, nbp, idx,
+                           dist, good, n_match, every);
 }
 
 __global__ __launch_bounds__(256) void knn2_merge_kernel(const int32_t* __restrict__ qcounts,

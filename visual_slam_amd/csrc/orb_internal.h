@@ -107,5 +107,12 @@ void launch_knn2(const Knn2Args& a, hipStream_t s);
 // `desc` (rows per frame = cap, row counts from counts[2 f + 1]; or n_fixed rows when counts == NULL)
 void launch_knn2_mfma(const Knn2Args& a, hipStream_t s);
 void launch_knn2_merge(const Knn2Args& a, hipStream_t s);
+// Measurement launch: launch_describe_tiles for one batch and launch_knn2_mfma over the consecutive pairs of
+// another feature buffer (mdesc [mframes][mcap][32], mcounts [mframes][2]) as ONE kernel with role-specialised
+// workgroups; qt = query tiles per wave of the matcher role (4 or 2).
+void launch_describe_match(const FrameSet& fs, const int2* kpxy, const int32_t* kpslot, const int32_t* counts, int cap,
+                           const int2* rowoff, float* kp7, uint8_t* desc, int32_t* valid_idx, const uint8_t* mdesc,
+                           const int32_t* mcounts, int mframes, int mcap, int32_t* idx, int32_t* dist, uint8_t* good,
+                           int qt, hipStream_t s);
 
 }  // namespace orbamd
