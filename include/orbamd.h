@@ -93,8 +93,8 @@ int orbamd_ctx_set_matcher(orbamd_ctx* ctx, int matcher);
  *   wrap      0 / 1        whether a run may continue from k = 15 to k = 0
  *   nms       0 / 1        keep a corner only if its score (the largest threshold it would still pass)
  *                          is strictly greater than the scores of its 8 neighbours
- * (20, 12, 0, 0) is the reference's detector and runs its bit-exact kernel; anything else runs separate,
- * simpler kernels and costs a byte per pixel of scratch memory.  Keypoint order, orientation and
+ * (20, 12, 0, 0) is the reference's detector and runs its bit-exact kernel; anything else runs a separate
+ * tile kernel (scores and suppression in LDS, no scratch memory).  Keypoint order, orientation and
  * descriptors are computed as always. */
 int orbamd_ctx_set_detector(orbamd_ctx* ctx, int threshold, int arc, int wrap, int nms);
 

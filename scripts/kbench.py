@@ -23,9 +23,13 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--cap", type=int, default=8192)
     ap.add_argument("--scene", default="sparse", choices=["sparse", "textured"])
+    ap.add_argument("--detector", default="", help="detector extension as threshold,arc,wrap,nms (e.g. 20,9,1,1)")
     a = ap.parse_args()
     P = synth.PRESETS[a.preset]
     eng = OrbEngine(0, cap=a.cap)
+    if a.detector:
+        thr, arc, wrap, nms = (int(v) for v in a.detector.split(","))
+        eng.ctx.set_detector(thr, arc, bool(wrap), bool(nms))
     if a.scene == "textured":
         gray = eng.synth_textured_frames(a.frames, P["H"], P["W"])
     else:

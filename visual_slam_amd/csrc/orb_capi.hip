@@ -49,7 +49,7 @@ struct orbamd_ctx {
     std::string err;
 
     // work buffers
-    DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle, score;
+    DevBuf gray, bgr, mask, rowcnt, rowoff, kpxy, kpslot, counts, kp7, desc, vidx, angle;
     DevBuf q, t, idx, dist, good, partial, rq, rt2, rt1, rcount, risk;
     bool audit = false;       // parity audit on: the describe kernels count near-midpoint narrowings into `risk`
     int risk_frames = 0;      // frames the last audited call covered
@@ -290,7 +290,6 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     CHK(ensure(c, c->rowoff, (size_t)frames * H * sizeof(int2)));
     FrameSet fs{d_gray, frames, H, W};
     const bool reference_detector = c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms;
-    if (!reference_detector) CHK(ensure(c, c->score, (size_t)frames * H * W));
     {
         // the row totals start from zero; the fill is timed under its own kind, not as part of the detector
         Timed t(c, ORBAMD_K_ROWCOUNT);
@@ -299,10 +298,10 @@ int run_detect_counts(orbamd_ctx* c, const uint8_t* d_gray, int frames, int H, i
     {
         Timed t(c, ORBAMD_K_FAST);
         if (reference_detector) launch_fast_mask(fs, (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
-        else launch_fast_ext(fs, c->det_thr, c->det_arc, c->det_wrap, c->det_nms, (uint8_t*)c->score.p,
-                             (uint32_t*)c->mask.p, (int2*)c->rowcnt.p, c->stream);
+        else launch_fast_ext(fs, c->det_thr, c->det_arc, c->det_wrap, c->det_nms, (uint32_t*)c->mask.p,
+                             (int2*)c->rowcnt.p, c->stream);
     }
-    CHK(post_launch(c, reference_detector ? "fast_mask_kernel" : "fastx kernels"));
+    CHK(post_launch(c, reference_detector ? "fast_mask_kernel" : "fastx_tile_kernel"));
     {
         Timed t(c, ORBAMD_K_ROWSCAN);
         launch_rowscan(fs, (const int2*)c->rowcnt.p, (int2*)c->rowoff.p, d_counts, c->stream);
@@ -604,7 +603,7 @@ int orbamd_ctx_destroy(orbamd_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->gray, &c->bgr, &c->mask, &c->rowcnt, &c->rowoff, &c->kpxy, &c->kpslot, &c->counts,
-                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->score, &c->q, &c->t, &c->idx, &c->dist, &c->good,
+                      &c->kp7, &c->desc, &c->vidx, &c->angle, &c->q, &c->t, &c->idx, &c->dist, &c->good,
                       &c->partial, &c->rq, &c->rt2, &c->rt1, &c->rcount, &c->risk};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -644,9 +643,6 @@ int orbamd_ctx_reserve(orbamd_ctx* c, int frames, int H, int W, int cap)
         }
         if (need) CHK(ensure(c, c->partial, need));
     }
-    // the score map of the detector extension, when one is selected
-    if (!(c->det_thr == 20 && c->det_arc == 12 && !c->det_wrap && !c->det_nms))
-        CHK(ensure(c, c->score, (size_t)frames * H * W));
     return ORBAMD_OK;
 }
 

@@ -894,119 +894,172 @@ void launch_emit(const FrameSet& fs, const uint32_t* mask, const int2* rowcnt, c
 // (src/orb.cpp:39, :70-96; the OpenCV call with suppression is commented out at :104-105).
 //
 // score(p) = largest t for which p passes the segment test with threshold t (inclusive compares) =
-// max over the allowed runs of the smallest one-signed |difference| in the run; stored as a byte, 0
-// where it is below the threshold.  Two plain kernels: the score map, then mask bits (+ the row
-// totals the ordered compaction needs) from the score map, with or without suppression.
+// max over the allowed runs of the smallest one-signed |difference| in the run; kept as a byte, 0
+// where it is below the threshold.
 // ---------------------------------------------------------------------------------------------
-constexpr int FX_W = 64, FX_H = 16, FX_PITCH = FX_W + 8;
+constexpr int FX_W = 64, FX_H = 16;                  // outputs per workgroup: one mask row of a tile = one wave's ballot
+constexpr int FX_PW = FX_W + 8, FX_PH = FX_H + 8;    // pixel tile: columns x0 - 4 .. x0 + 67 (18 dwords), rows y0 - 4 .. y0 + 19
+constexpr int FX_SW = FX_W + 2, FX_SH = FX_H + 2;    // score region: one pixel more on every side, for the suppression
+constexpr int FX_SP = 68;                            // score row pitch in bytes
 
-__global__ __launch_bounds__(256) void fastx_score_kernel(const uint8_t* __restrict__ gray, int H, int W,
-                                                          int thr, int arc, int wrap, uint8_t* __restrict__ score,
-                                                          int ntc, int ntr)
+// Circle offsets in the pixel tile (pitch FX_PW), k = 0 at (0,-3), clockwise.
+__device__ __forceinline__ constexpr int fx_off(int k)
 {
-    __shared__ uint8_t tile[(FX_H + 6) * FX_PITCH];
-    const uint32_t item = blockIdx.x;
+    constexpr int dxk[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int dyk[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    return dyk[k] * FX_PW + dxk[k];
+}
+
+// Cheap screen: any run of >= 9 circle pixels holds two neighbouring compass points (k = 0, 4, 8, 12) of
+// its sign, so a pixel without such a pair scores 0.
+__device__ __forceinline__ bool fastx_screen(const uint8_t* c, int thr)
+{
+    const int p = c[0];
+    const int d0 = (int)c[fx_off(0)] - p, d4 = (int)c[fx_off(4)] - p, d8 = (int)c[fx_off(8)] - p, d12 = (int)c[fx_off(12)] - p;
+    const bool b0 = d0 >= thr, b4 = d4 >= thr, b8 = d8 >= thr, b12 = d12 >= thr;
+    const bool k0 = d0 <= -thr, k4 = d4 <= -thr, k8 = d8 <= -thr, k12 = d12 <= -thr;
+    return (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
+}
+
+// max over the runs k = s .. s + ARC - 1 (s < nstarts, indices mod 16) of the smallest e[k] in the run: window
+// minima of length 2, 4, 8 by doubling, and a run of 9 .. 16 as two overlapping windows of 8.
+template <int ARC>
+__device__ __forceinline__ int fastx_best_run(const int (&e)[16], int nstarts)
+{
+    int a[16], b[16], c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b[k] = min(a[k], a[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = min(b[k], b[(k + 4) & 15]);
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int w = min(c[k], c[(k + ARC - 8) & 15]);
+        if (k < nstarts) best = max(best, w);
+    }
+    return best;
+}
+
+// Score of the pixel at LDS position c (pixel tile, pitch FX_PW): see above.
+template <int ARC>
+__device__ __forceinline__ int fastx_score(const uint8_t* c, int thr, int nstarts)
+{
+    const int p = c[0];
+    int d[16], nd[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { d[k] = (int)c[fx_off(k)] - p; nd[k] = -d[k]; }
+    const int best = max(fastx_best_run<ARC>(d, nstarts), fastx_best_run<ARC>(nd, nstarts));
+    return best < thr ? 0 : (best > 255 ? 255 : best);
+}
+
+__device__ __forceinline__ int fastx_score_arc(const uint8_t* c, int thr, int arc, int nstarts)
+{
+    switch (arc) {                       // (uniform over the launch)
+        case 9: return fastx_score<9>(c, thr, nstarts);
+        case 10: return fastx_score<10>(c, thr, nstarts);
+        case 11: return fastx_score<11>(c, thr, nstarts);
+        case 12: return fastx_score<12>(c, thr, nstarts);
+        case 13: return fastx_score<13>(c, thr, nstarts);
+        case 14: return fastx_score<14>(c, thr, nstarts);
+        case 15: return fastx_score<15>(c, thr, nstarts);
+        default: return fastx_score<16>(c, thr, nstarts);
+    }
+}
+
+// One workgroup per 64 x 16 tile: pixels (with a 4-pixel halo) staged in LDS by dword loads, scores of the
+// tile and of the ring of pixels around it computed into LDS, then one wave per mask row: the ballot of
+// "kept" over the 64 lanes IS the row's two mask words.  The score map never exists in device memory.  Also
+// adds the tile's (corners, corners with a descriptor) to the row totals (rowcnt zeroed before the launch).
+__global__ __launch_bounds__(256) void fastx_tile_kernel(const uint8_t* __restrict__ gray, int H, int W, int thr,
+                                                         int arc, int wrap, int nms, uint32_t* __restrict__ mask,
+                                                         int MW, unsigned long long* __restrict__ rowcnt, int ntc,
+                                                         int ntr, int dwords)
+{
+    __shared__ uint32_t pix32[FX_PH * FX_PW / 4];
+    __shared__ uint8_t sc[FX_SH * FX_SP];
+    __shared__ uint16_t cand[FX_SW * FX_SH];
+    __shared__ int ncand;
+    if (threadIdx.x == 0) ncand = 0;
+    const uint32_t item = xcd_contiguous_item();
     const int bx = (int)(item % (uint32_t)ntc);
     const uint32_t rest = item / (uint32_t)ntc;
     const int by = (int)(rest % (uint32_t)ntr);
     const size_t f = rest / (uint32_t)ntr;
     const uint8_t* img = gray + f * H * W;
-    uint8_t* out = score + f * H * W;
     const int x0 = bx * FX_W, y0 = by * FX_H;
-    for (int i = threadIdx.x; i < (FX_H + 6) * (FX_W + 6); i += 256) {
-        const int r = i / (FX_W + 6), c = i - r * (FX_W + 6);
-        const int y = y0 - 3 + r, x = x0 - 3 + c;
-        tile[r * FX_PITCH + c] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : (uint8_t)0;
+    const int t = (int)threadIdx.x;
+    for (int i = t; i < FX_PH * (FX_PW / 4); i += 256) {
+        const int row = i / (FX_PW / 4), dw = i - row * (FX_PW / 4);
+        const int y = y0 - 4 + row, x = x0 - 4 + 4 * dw;
+        uint32_t v = 0u;
+        if (y >= 0 && y < H) {
+            if (dwords) {
+                if (x >= 0 && x < W) v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * W + x);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (x + b >= 0 && x + b < W) v |= (uint32_t)img[(size_t)y * W + x + b] << (8 * b);
+            }
+        }
+        pix32[i] = v;
     }
     __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint8_t* pix = reinterpret_cast<const uint8_t*>(pix32);
     const int nstarts = wrap ? 16 : 16 - arc + 1;
-    constexpr int dxk[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    constexpr int dyk[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
-    for (int rr = 0; rr < FX_H / 4; ++rr) {
-        const int r = ty * (FX_H / 4) + rr;
-        const int x = x0 + tx, y = y0 + r;
-        if (x >= W || y >= H) continue;
-        int best = 0;
-        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
-            const uint8_t* c = tile + (r + 3) * FX_PITCH + tx + 3;
-            const int p = c[0];
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = (int)c[dyk[k] * FX_PITCH + dxk[k]] - p;
-            // any run of >= 9 holds two neighbouring compass points (k = 0, 4, 8, 12) of its sign
-            const bool b0 = d[0] >= thr, b4 = d[4] >= thr, b8 = d[8] >= thr, b12 = d[12] >= thr;
-            const bool k0 = d[0] <= -thr, k4 = d[4] <= -thr, k8 = d[8] <= -thr, k12 = d[12] <= -thr;
-            if ((b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) ||
-                (k12 && k0)) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (s < nstarts) {
-                        int mb = 255, md = 255;
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            if (j < arc) {
-                                const int dd = d[(s + j) & 15];
-                                mb = mb < dd ? mb : dd;
-                                md = md < -dd ? md : -dd;
-                            }
-                        }
-                        const int m = mb > md ? mb : md;
-                        best = best > m ? best : m;
-                    }
-                }
-            }
-            if (best < thr) best = 0;
-        }
-        out[(size_t)y * W + x] = (uint8_t)best;
+    // screen every position of the score region; the few that pass are listed and scored with all lanes busy
+    for (int i = t; i < FX_SW * FX_SH; i += 256) {
+        const int r = i / FX_SW, c = i - r * FX_SW;
+        const int x = x0 - 1 + c, y = y0 - 1 + r;
+        sc[r * FX_SP + c] = 0;
+        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3 && fastx_screen(pix + (r + 3) * FX_PW + c + 3, thr))
+            cand[atomicAdd(&ncand, 1)] = (uint16_t)((r << 8) | c);
     }
-}
-
-// One thread per mask word: bit b = pixel 32 w + b kept.  Also adds the word's (corners, corners
-// with a descriptor) to the row totals (rowcnt zeroed before the launch).
-__global__ __launch_bounds__(256) void fastx_mask_kernel(const uint8_t* __restrict__ score, int H, int W, int MW,
-                                                         int nms, long nwords, uint32_t* __restrict__ mask,
-                                                         unsigned long long* __restrict__ rowcnt)
-{
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= nwords) return;
-    const int w = (int)(id % MW);
-    const long row = id / MW;                         // f * H + y
-    const int y = (int)(row % H);
-    const uint8_t* sc = score + (row - y) * (long)W;  // the frame's score map
-    uint32_t bits = 0u;
-    for (int b = 0; b < 32; ++b) {
-        const int x = 32 * w + b;
-        if (x >= W) break;
-        const int s = sc[(long)y * W + x];
-        bool keep = s > 0;
+    __syncthreads();
+    for (int j = t; j < ncand; j += 256) {
+        const int r = cand[j] >> 8, c = cand[j] & 255;
+        sc[r * FX_SP + c] = (uint8_t)fastx_score_arc(pix + (r + 3) * FX_PW + c + 3, thr, arc, nstarts);
+    }
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const int wi = x0 >> 5;
+    uint32_t* mfr = mask + f * H * MW;
+    unsigned long long* const rc = rowcnt + f * H;
+    for (int row = wave; row < FX_H; row += 4) {
+        const int y = y0 + row;
+        if (y >= H) break;                                        // (wave-uniform)
+        const uint8_t* sp = sc + (row + 1) * FX_SP + lane + 1;
+        const int s = sp[0];
+        bool keep = s > 0 && x0 + lane < W;
         if (keep && nms) {
-            for (int dy = -1; dy <= 1 && keep; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = y + dy, xx = x + dx;
-                    if ((dx || dy) && yy >= 0 && yy < H && xx >= 0 && xx < W && (int)sc[(long)yy * W + xx] >= s) keep = false;
-                }
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+                    if ((dx || dy) && (int)sp[dy * FX_SP + dx] >= s) keep = false;
         }
-        if (keep) bits |= 1u << b;
-    }
-    mask[id] = bits;
-    if (bits) {
-        const bool yv = (y - 16 >= 0) && (y + 16 < H);
-        const uint32_t v = yv ? (uint32_t)__popc(bits & desc_column_bits(w, W)) : 0u;
-        atomicAdd(rowcnt + row, (unsigned long long)(uint32_t)__popc(bits) | ((unsigned long long)v << 32));
+        const unsigned long long bits = __ballot(keep);
+        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        if (lane == 0) {
+            if (wi < MW) mfr[(size_t)y * MW + wi] = lo;
+            if (wi + 1 < MW) mfr[(size_t)y * MW + wi + 1] = hi;
+            if (bits) {
+                const bool yv = (y - 16 >= 0) && (y + 16 < H);
+                const uint32_t v = yv ? (uint32_t)(__popc(lo & desc_column_bits(wi, W)) + __popc(hi & desc_column_bits(wi + 1, W))) : 0u;
+                atomicAdd(rc + y, (unsigned long long)(uint32_t)__popcll(bits) | ((unsigned long long)v << 32));
+            }
+        }
     }
 }
 
-void launch_fast_ext(const FrameSet& fs, int thr, int arc, int wrap, int nms, uint8_t* score, uint32_t* mask,
-                     int2* rowcnt, hipStream_t s)
+void launch_fast_ext(const FrameSet& fs, int thr, int arc, int wrap, int nms, uint32_t* mask, int2* rowcnt, hipStream_t s)
 {
     const int ntc = (fs.W + FX_W - 1) / FX_W, ntr = (fs.H + FX_H - 1) / FX_H;
-    hipLaunchKernelGGL(fastx_score_kernel, dim3((unsigned)((size_t)ntc * ntr * fs.frames)), dim3(256), 0, s, fs.gray,
-                       fs.H, fs.W, thr, arc, wrap, score, ntc, ntr);
-    const int MW = mask_words(fs.W);
-    const long nwords = (long)fs.frames * fs.H * MW;
-    hipLaunchKernelGGL(fastx_mask_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, score, fs.H, fs.W,
-                       MW, nms, nwords, mask, reinterpret_cast<unsigned long long*>(rowcnt));
+    const int dwords = ((fs.W & 3) == 0) && (((uintptr_t)fs.gray & 3) == 0);
+    hipLaunchKernelGGL(fastx_tile_kernel, dim3((unsigned)((size_t)ntc * ntr * fs.frames)), dim3(256), 0, s, fs.gray, fs.H,
+                       fs.W, thr, arc, wrap, nms, mask, mask_words(fs.W), reinterpret_cast<unsigned long long*>(rowcnt),
+                       ntc, ntr, dwords);
 }
 
 // Descriptor rows for a caller-supplied keypoint list (any order): slot = rank among keypoints

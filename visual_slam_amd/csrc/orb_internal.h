@@ -45,9 +45,9 @@ void launch_synth(uint8_t* gray, int frames, int H, int W, int first_frame, uint
 // Also accumulates rowcnt[frame][y] = (corners, corners with a descriptor); rowcnt must be zero.
 void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStream_t s);
 // Detector extension (arc length, wrap, threshold, score + 3x3 non-maximum suppression): fills mask and
-// rowcnt like launch_fast_mask; score is [frames][H][W] bytes of scratch.  rowcnt must be zero.
-void launch_fast_ext(const FrameSet& fs, int thr, int arc, int wrap, int nms, uint8_t* score, uint32_t* mask,
-                     int2* rowcnt, hipStream_t s);
+// rowcnt like launch_fast_mask.  rowcnt must be zero.
+void launch_fast_ext(const FrameSet& fs, int thr, int arc, int wrap, int nms, uint32_t* mask, int2* rowcnt,
+                     hipStream_t s);
 void launch_rowscan(const FrameSet& fs, const int2* rowcnt, int2* rowoff, int32_t* counts, hipStream_t s);
 // counts [frames][2] as written by launch_rowscan; a frame with more than cap keypoints gets its
 // second entry replaced by the number of descriptor rows that belong to its first cap keypoints.
