@@ -15,9 +15,9 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $OUT -o write --output-format 
 python3 scripts/collect_traffic.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/traffic.json > $OUT/traffic.txt
 # bench.py reads the traffic figures from profiles/: use the ones just measured on this build
 cp $OUT/traffic.json $R/profiles/${ROUND}_pmc_traffic_1080p_1000frames.json
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 bench.py --textured-frames 0 > $OUT/bench_under_rocprof.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o stats --output-format csv -- python3 bench.py --textured-frames 0 --dropin-calls 0 > $OUT/bench_under_rocprof.log 2>&1
 # The same with the textured-scene leg (its launches are longer: separate trace so the averages above stay those of the headline workload).
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o textured --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_textured_under_rocprof.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o textured --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --dropin-calls 0 > $OUT/bench_textured_under_rocprof.log 2>&1
 # The pipelined variant (frame ranges on two streams), for comparison.
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o pipelined --output-format csv -- python3 bench.py --chunks 4 --textured-frames 0 > $OUT/bench_pipelined_under_rocprof.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o pipelined --output-format csv -- python3 bench.py --chunks 4 --textured-frames 0 --dropin-calls 0 > $OUT/bench_pipelined_under_rocprof.log 2>&1
 cat $OUT/traffic.txt

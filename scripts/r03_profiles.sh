@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-3 evidence: everything README / DESIGN quote, collected in one go on the GPU box and copied to profiles/.
+#   bash scripts/r03_profiles.sh      (results under gpurun_out/r03_prof/ and gpurun_out/prof_r03/, pmc_r03/)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r03_prof
+mkdir -p $OUT
+cd $R
+# traffic + kernel stats of the default bench (+ textured leg, + pipelined variant)
+bash scripts/profile_round.sh r03 r03 > $OUT/profile_round.log 2>&1 || { tail -20 $OUT/profile_round.log; exit 1; }
+bash scripts/pmc_insts.sh r03 > $OUT/pmc_insts.log 2>&1 || { tail -20 $OUT/pmc_insts.log; exit 1; }
+cp gpurun_out/pmc_r03/instruction_mix.json profiles/r03_pmc_instruction_mix_1080p_1000frames.json
+cd /tmp && export TMPDIR=/tmp
+cd $R
+# other workloads: bench line + kernel stats each
+for w in "480p --preset 480p" "4k --preset 4k --frames 200" "dense --workload dense-match"; do
+  set -- $w; tag=$1; shift
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT -o $tag --output-format csv -- python3 bench.py "$@" --steps 10 --warmup 3 --textured-frames 0 --dropin-calls 0 --cpu-sample 8 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err || { tail -5 $OUT/bench_$tag.err; exit 1; }
+  tail -1 $OUT/bench_$tag.json | python3 -c "import json,sys; d=json.load(sys.stdin); print('$tag', d['value'], d['unit'], d['ms_per_step'])"
+done
+# one call of the reference's call shape: kernel + memory-copy trace
+timeout -s KILL 200 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT -o dropin --output-format csv -- python3 scripts/dropin_rate.py --calls 4 > $OUT/dropin_trace.log 2>&1 || { tail -5 $OUT/dropin_trace.log; exit 1; }
+ls $OUT

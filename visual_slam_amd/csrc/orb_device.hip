@@ -1180,6 +1180,68 @@ __device__ __forceinline__ Tri32 load_tri_at(const uint8_t* __restrict__ base, u
     return *reinterpret_cast<const Tri32*>(base + off);
 }
 
+// The arithmetic of the 16-lanes-per-keypoint patch moments, shared by the kernel that fetches patch rows from
+// global memory and the one that reads them from an LDS tile.  Lane q < 15 of a keypoint's group of 16 =
+// (row slot rs = q / 3, chunk ch = q % 3): it holds dwords 3 ch .. 3 ch + 2 of patch rows rs, rs + 5, ...,
+// rs + 30 (pix[it].v[j]; anything may be in a dword whose row is outside the patch or the image as long as the
+// caller passes it as 0), the 31 columns starting `r` bytes into dword 0.  Per dword: m00 += sum of bytes
+// (v_sad_u8, accumulating), m10' += bytes . (u + 16) (v_dot4_u32_u8); only dwords 0, 7 and 8 contain bytes
+// outside the 31 columns.  m01 += v * rowsum per row.  The three sums are then reduced over the 16 lanes of a
+// DPP row (4 steps); the totals come out in lane 15 of each row of 16.
+struct MomentLane {
+    uint32_t mk[3], w[3];
+    int rs;
+};
+__device__ __forceinline__ MomentLane moment_lane(int r, int q, bool lane_on)
+{
+    MomentLane m;
+    const int ch = q < 15 ? q % 3 : 0;
+    m.rs = q < 15 ? q / 3 : 0;
+    // column offset t = 4 c + byte is inside the patch iff r <= t <= 30 + r: partial dwords are
+    // c = 0 (chunk 0, first), c = 7 and c = 8 (chunk 2, second and third)
+    m.mk[0] = m.mk[1] = m.mk[2] = 0xFFFFFFFFu;
+    if (ch == 0) m.mk[0] = 0xFFFFFFFFu << (8 * r);
+    if (ch == 2) {
+        m.mk[1] = r == 0 ? 0x00FFFFFFu : 0xFFFFFFFFu;
+        m.mk[2] = r < 2 ? 0u : (r == 2 ? 0x000000FFu : 0x0000FFFFu);
+    }
+    if (!lane_on) { m.mk[0] = 0u; m.mk[1] = 0u; m.mk[2] = 0u; }
+    // weights u + 16 = t - r + 1 per byte.  In dword 0 the bytes left of the patch would get
+    // negative weights (their borrows would spill into valid bytes), so that word is the r = 0
+    // pattern {1,2,3,4} shifted up by r bytes; from dword 1 on every weight is >= 2.
+#pragma unroll
+    for (int j = 0; j < 3; ++j)       // the byte 4 (3 ch + j) - r + 1 in all four lanes, plus 0 1 2 3
+        m.w[j] = __builtin_amdgcn_perm(0u, (uint32_t)(4 * (3 * ch + j) - r + 1), 0u) + 0x03020100u;
+    if (ch == 0) m.w[0] = 0x04030201u << (8 * r);
+    return m;
+}
+
+// One row slot's dword j of step `it` into the running sums (rsum = this row's byte sum so far).
+__device__ __forceinline__ void moment_dword(const MomentLane& m, uint32_t v, int j, uint32_t& rsum, uint32_t& t10)
+{
+    const uint32_t pm = v & m.mk[j];
+    rsum = __builtin_amdgcn_sad_u8(pm, 0u, rsum);
+    t10 = __builtin_amdgcn_udot4(pm, m.w[j], t10, false);
+}
+
+__device__ __forceinline__ void moment_row(const MomentLane& m, int it, uint32_t rsum, uint32_t& t00, int& t01)
+{
+    t00 += rsum;
+    t01 += __mul24(m.rs + 5 * it - 15, (int)rsum);
+}
+
+// (t00, t10', t01) of one lane -> (m00, m10, m01) summed over the row of 16 lanes, in its lane 15.
+__device__ __forceinline__ void moment_reduce(uint32_t t00, uint32_t t10, int t01, int& s00, int& s10, int& s01)
+{
+    s00 = (int)t00;
+    s10 = (int)t10 - 16 * s00;
+    s01 = t01;
+    s00 = dpp_add<0x111, 0xf>(s00); s10 = dpp_add<0x111, 0xf>(s10); s01 = dpp_add<0x111, 0xf>(s01);
+    s00 = dpp_add<0x112, 0xf>(s00); s10 = dpp_add<0x112, 0xf>(s10); s01 = dpp_add<0x112, 0xf>(s01);
+    s00 = dpp_add<0x114, 0xf>(s00); s10 = dpp_add<0x114, 0xf>(s10); s01 = dpp_add<0x114, 0xf>(s01);
+    s00 = dpp_add<0x118, 0xf>(s00); s10 = dpp_add<0x118, 0xf>(s10); s01 = dpp_add<0x118, 0xf>(s01);
+}
+
 // Patch moments on the dword path (rows are whole aligned dwords: W % 4 == 0 and a 4-byte-aligned
 // frame): FOUR keypoints per step, 16 lanes each.  The 31 columns x-15 .. x+15 lie inside 9 aligned
 // dwords starting at xa = (x-15) & ~3.  Lane q of a group = (row slot rs = q / 3, chunk ch = q % 3):
@@ -1194,24 +1256,9 @@ __device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ i
 {
     const int r = (x - 15) & 3;
     const int xa = (x - 15) - r;              // aligned start column (may be negative)
-    const int rs = q < 15 ? q / 3 : 0, ch = q < 15 ? q % 3 : 0;
     const bool lane_on = group_valid && q < 15;
-    // column offset t = 4 c + byte is inside the patch iff r <= t <= 30 + r: partial dwords are
-    // c = 0 (chunk 0, first), c = 7 and c = 8 (chunk 2, second and third)
-    uint32_t mk[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (ch == 0) mk[0] = 0xFFFFFFFFu << (8 * r);
-    if (ch == 2) {
-        mk[1] = r == 0 ? 0x00FFFFFFu : 0xFFFFFFFFu;
-        mk[2] = r < 2 ? 0u : (r == 2 ? 0x000000FFu : 0x0000FFFFu);
-    }
-    if (!lane_on) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; }
-    // weights u + 16 = t - r + 1 per byte.  In dword 0 the bytes left of the patch would get
-    // negative weights (their borrows would spill into valid bytes), so that word is the r = 0
-    // pattern {1,2,3,4} shifted up by r bytes; from dword 1 on every weight is >= 2.
-    uint32_t w[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) w[j] = (uint32_t)(4 * (3 * ch + j) - r + 1) * 0x01010101u + 0x03020100u;
-    if (ch == 0) w[0] = 0x04030201u << (8 * r);
+    const MomentLane m = moment_lane(r, q, lane_on);
+    const int rs = m.rs, ch = q < 15 ? q % 3 : 0;
 
     const int gx = xa + 12 * ch, gy0 = y - 15 + rs;
     Tri32 pix[7];
@@ -1221,7 +1268,7 @@ __device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ i
         const uint32_t off = lane_on ? (uint32_t)(gy0 * W + gx) : 0u;
 #pragma unroll
         for (int it = 0; it < 6; ++it) pix[it] = load_tri_at(img, off + (lane_on ? (uint32_t)(5 * it * W) : 0u));
-        // rows 30 .. 34: only row slot 0 is still inside the patch (the others get zero masks below)
+        // rows 30 .. 34: only row slot 0 is still inside the patch (the others are masked out below)
         pix[6] = load_tri_at(img, (lane_on && rs == 0) ? off + (uint32_t)(30 * W) : off);
     } else if (__all((xa >= 0 && xa <= W - 36) || !group_valid)) {
         // clipped at the top or bottom edge only: whole 12-byte loads, rows outside the image read as 0
@@ -1250,23 +1297,12 @@ __device__ __forceinline__ void patch_moments_quad(const uint8_t* __restrict__ i
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
         uint32_t rsum = 0;
+        const bool rowin = it < 6 || rs == 0;       // rows 30 .. 34: only row 30 is in the patch
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t pm = pix[it].v[j] & ((it == 6 && rs != 0) ? 0u : mk[j]);
-            rsum = __builtin_amdgcn_sad_u8(pm, 0u, rsum);
-            t10 = __builtin_amdgcn_udot4(pm, w[j], t10, false);
-        }
-        t00 += rsum;
-        t01 += __mul24(rs + 5 * it - 15, (int)rsum);
+        for (int j = 0; j < 3; ++j) moment_dword(m, rowin ? pix[it].v[j] : 0u, j, rsum, t10);
+        moment_row(m, it, rsum, t00, t01);
     }
-    s00 = (int)t00;
-    s10 = (int)t10 - 16 * s00;
-    s01 = t01;
-    // sums over each row of 16 lanes; lane 15 of the row ends up with the total
-    s00 = dpp_add<0x111, 0xf>(s00); s10 = dpp_add<0x111, 0xf>(s10); s01 = dpp_add<0x111, 0xf>(s01);
-    s00 = dpp_add<0x112, 0xf>(s00); s10 = dpp_add<0x112, 0xf>(s10); s01 = dpp_add<0x112, 0xf>(s01);
-    s00 = dpp_add<0x114, 0xf>(s00); s10 = dpp_add<0x114, 0xf>(s10); s01 = dpp_add<0x114, 0xf>(s01);
-    s00 = dpp_add<0x118, 0xf>(s00); s10 = dpp_add<0x118, 0xf>(s10); s01 = dpp_add<0x118, 0xf>(s01);
+    moment_reduce(t00, t10, t01, s00, s10, s01);
 }
 
 // Any width / alignment: one byte per lane and step.
@@ -1804,20 +1840,8 @@ __device__ __forceinline__ void describe_tile_body(
                         const int lx = (int)(pxy & 0xFFFFu), ly = (int)(pxy >> 16);
                         const int r = (lx - 15) & 3;
                         const int xa = (lx - 15) - r;
-                        const int rs = q < 15 ? q / 3 : 0, ch = q < 15 ? q % 3 : 0;
-                        const bool lane_on = valid && q < 15;
-                        uint32_t mk[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                        if (ch == 0) mk[0] = 0xFFFFFFFFu << (8 * r);
-                        if (ch == 2) {
-                            mk[1] = r == 0 ? 0x00FFFFFFu : 0xFFFFFFFFu;
-                            mk[2] = r < 2 ? 0u : (r == 2 ? 0x000000FFu : 0x0000FFFFu);
-                        }
-                        if (!lane_on) { mk[0] = 0u; mk[1] = 0u; mk[2] = 0u; }
-                        uint32_t w[3];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)       // the byte 4 (3 ch + j) - r + 1 in all four lanes, plus 0 1 2 3
-                            w[j] = __builtin_amdgcn_perm(0u, (uint32_t)(4 * (3 * ch + j) - r + 1), 0u) + 0x03020100u;
-                        if (ch == 0) w[0] = 0x04030201u << (8 * r);
+                        const MomentLane ml = moment_lane(r, q, valid && q < 15);
+                        const int rs = ml.rs, ch = q < 15 ? q % 3 : 0;
                         const uint32_t* src = tile32 + __mul24(ly - 15 + rs, DT_PITCH_DW) + (xa >> 2) + 3 * ch;
                         uint32_t t00 = 0, t10 = 0;
                         int t01 = 0;
@@ -1826,19 +1850,12 @@ __device__ __forceinline__ void describe_tile_body(
                             uint32_t rsum = 0;
                             const bool rowin = it < 6 || rs == 0;       // rows 30 .. 34: only row 30 is in the patch
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const uint32_t pm = (rowin ? src[5 * it * DT_PITCH_DW + j] : 0u) & mk[j];
-                                rsum = __builtin_amdgcn_sad_u8(pm, 0u, rsum);
-                                t10 = __builtin_amdgcn_udot4(pm, w[j], t10, false);
-                            }
-                            t00 += rsum;
-                            t01 += __mul24(rs + 5 * it - 15, (int)rsum);
+                            for (int j = 0; j < 3; ++j)
+                                moment_dword(ml, rowin ? src[5 * it * DT_PITCH_DW + j] : 0u, j, rsum, t10);
+                            moment_row(ml, it, rsum, t00, t01);
                         }
-                        int s00 = (int)t00, s10 = (int)t10 - 16 * (int)t00, s01 = t01;
-                        s00 = dpp_add<0x111, 0xf>(s00); s10 = dpp_add<0x111, 0xf>(s10); s01 = dpp_add<0x111, 0xf>(s01);
-                        s00 = dpp_add<0x112, 0xf>(s00); s10 = dpp_add<0x112, 0xf>(s10); s01 = dpp_add<0x112, 0xf>(s01);
-                        s00 = dpp_add<0x114, 0xf>(s00); s10 = dpp_add<0x114, 0xf>(s10); s01 = dpp_add<0x114, 0xf>(s01);
-                        s00 = dpp_add<0x118, 0xf>(s00); s10 = dpp_add<0x118, 0xf>(s10); s01 = dpp_add<0x118, 0xf>(s01);
+                        int s00, s10, s01;
+                        moment_reduce(t00, t10, t01, s00, s10, s01);
                         if (valid && q == 15) {
                             int* m = reinterpret_cast<int*>(&cs[e]);
                             m[0] = s00; m[1] = s10; m[2] = s01;
