@@ -49,8 +49,8 @@ def lib():
         L.orc_knn2.restype = None
         L.orc_ratio_filter.argtypes = [_i32p, _i32p, ctypes.c_long, _i32p, _i32p, _i32p]
         L.orc_ratio_filter.restype = ctypes.c_long
-        L.orc_pattern_pairs.argtypes = []
-        L.orc_pattern_pairs.restype = ctypes.POINTER(ctypes.c_int8)
+        L.orc_pattern_points.argtypes = []
+        L.orc_pattern_points.restype = ctypes.POINTER(ctypes.c_int8)
         _lib = L
     return _lib
 
@@ -194,6 +194,13 @@ def ratio_filter(idx, dist):
     return gq[:m].copy(), g2[:m].copy(), g1[:m].copy()
 
 
+def pattern_points():
+    """The restatement's own table: 512 points (x, y) in the reference's order."""
+    p = lib().orc_pattern_points()
+    return np.ctypeslib.as_array(p, shape=(512, 2)).copy()
+
+
 def pattern_pairs():
-    p = lib().orc_pattern_pairs()
-    return np.ctypeslib.as_array(p, shape=(256, 4)).copy()
+    """The same as 256 test pairs (x1, y1, x2, y2): pair k = point k against point k + 256."""
+    pts = pattern_points()
+    return np.concatenate([pts[:256], pts[256:]], axis=1)

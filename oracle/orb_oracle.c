@@ -30,11 +30,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../visual_slam_amd/csrc/orb_pattern.h"
+/* The restatement's own copy of the sampling table, in the reference's order and indexed the reference's
+ * way; the product keeps a re-laid-out copy of its own (visual_slam_amd/csrc/orb_pattern.h). */
+#include "orb_pattern_points.h"
 
 #define ORC_PI 3.1415926535897932384626433832795
-
-static const int8_t orc_pairs[ORBAMD_PATTERN_PAIRS * 4] = ORBAMD_PATTERN_QUADS_INIT;
 
 /* cvRound(float): round half to even, as the SSE path of OpenCV does. */
 static inline int orc_round_f(float v) { return (int)lrintf(v); }
@@ -179,8 +179,9 @@ void orc_describe_one(const uint8_t* gray, int H, int W, float cx, float cy, flo
         int byte_val = 0;
         for (int bit = 0; bit < 8; ++bit) {
             int k = byte * 8 + bit;
-            int p1x = orc_pairs[4 * k], p1y = orc_pairs[4 * k + 1];
-            int p2x = orc_pairs[4 * k + 2], p2y = orc_pairs[4 * k + 3];
+            /* Point p1 = pattern[k], p2 = pattern[k + 256] (reference src/orb.cpp:191-192) */
+            int p1x = orc_points[k][0], p1y = orc_points[k][1];
+            int p2x = orc_points[k + 256][0], p2y = orc_points[k + 256][1];
             float x1 = (float)(p1x * cos_theta - p1y * sin_theta);
             float y1 = (float)(p1x * sin_theta + p1y * cos_theta);
             float x2 = (float)(p2x * cos_theta - p2y * sin_theta);
@@ -314,5 +315,5 @@ long orc_ratio_filter(const int32_t* idx, const int32_t* dist, long nq, int32_t*
     return m;
 }
 
-/* Pair-major pattern table, for cross-checks from Python. */
-const int8_t* orc_pattern_pairs(void) { return orc_pairs; }
+/* The 512 sampling points (x, y) in the reference's order, for cross-checks from Python. */
+const signed char* orc_pattern_points(void) { return &orc_points[0][0]; }

@@ -1,5 +1,7 @@
 """The two CPU restatements (C, following the reference's loops; NumPy, closed-form) must agree bit
 for bit, and both must reproduce the committed golden fixtures.  No GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,9 +80,23 @@ def test_bgr2gray_agrees():
 
 
 def test_pattern_table_integrity():
-    """The sampling table is re-laid-out from the reference's 1024 integers; guard its content."""
+    """Three copies of the sampling table exist, all generated from the reference's 1024 integers: the C
+    restatement's own (reference order), the NumPy restatement's text file and the product's header (both
+    pair-major).  Guard the content of each against the digests of the reference's integers."""
     import hashlib
+    import re
+    pts = oracle.c.pattern_points()
+    assert pts.shape == (512, 2)
+    assert hashlib.sha256(pts.reshape(-1).astype("<i4").tobytes()).hexdigest() == \
+        "14a92c4fff1eeb6d126a65a063bc195ae5a86c259b4300eca1e6a5640eaf2c7c"
+    assert hashlib.sha256(pts.reshape(-1).astype(np.int8).tobytes()).hexdigest() == \
+        "96f37ade61dc2b1c02acea3a50df2c035bcf5a5b41bbb168e0550f36e2ad81e6"
+    header = open(os.path.join(os.path.dirname(os.path.abspath(np_ref.__file__)), "..", "visual_slam_amd", "csrc",
+                               "orb_pattern.h")).read()
+    body = header[header.index("ORBAMD_PATTERN_QUADS_INIT {"):]
+    product = np.array([int(v) for v in re.findall(r"-?\d+", body[body.index("{"):])], np.int64).reshape(256, 4)
     p = oracle.c.pattern_pairs()
+    assert np.array_equal(product, p)
     assert p.shape == (256, 4) and np.abs(p).max() == 15
     assert hashlib.sha256(p.astype(np.int8).tobytes()).hexdigest() == \
         "55641b1c693e01a789bba85a9ea8c16d5ceca6fa858f2d69ad2a8781c0cd5dda"
