@@ -16,7 +16,7 @@ MODULE := build/orb_project$(EXT_SUFFIX)
 
 all: $(LIB) $(MODULE) oracle
 
-$(LIB): $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip $(CSRC)/orb_internal.h $(CSRC)/orb_pattern.h include/orbamd.h
+$(LIB): $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip $(CSRC)/orb_internal.h $(CSRC)/orb_pattern.h $(CSRC)/orb_trig.h include/orbamd.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip
 
 $(MODULE): $(CSRC)/orb_module.cpp include/orbamd.h $(LIB)

@@ -22,6 +22,7 @@
 // x*c - y*s as two rounded products and one rounded difference (reference src/orb.cpp:195-199).
 #include "orb_internal.h"
 #include "orb_pattern.h"
+#include "orb_trig.h"
 
 #include <stdlib.h>
 
@@ -1143,12 +1144,23 @@ __device__ __forceinline__ uint32_t audit_coord(double v, float centre)
     return __float2int_rn(centre + f) != __float2int_rn(centre + g) ? 3u : 1u;
 }
 
+// The coefficient table of orb_trig.h behind a pointer the optimiser cannot trace: the table is then read by
+// scalar loads where it is used.  (Seen through, the 25 doubles are kept in vector registers for the whole
+// kernel, on top of the sampling pattern's 32.)
+typedef const __attribute__((address_space(4))) double* TrigTable;
+__device__ __forceinline__ TrigTable trig_table()
+{
+    TrigTable k = (TrigTable)orbtrig::COEF;
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 __device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01, bool* near_midpoint = nullptr)
 {
     if (near_midpoint) *near_midpoint = false;
     if (m00 == 0) return 0.0f;
-    double a = atan2((double)m01, (double)m10);
-    const double deg = a * (180.0 / ORB_PI);
+    bool unsure;
+    const double deg = orbtrig::atan2_deg_moments(m01, m10, unsure, trig_table());
     if (near_midpoint) *near_midpoint = near_float_midpoint(deg);
     float ang = (float)deg;
     if (ang < 0) ang = (float)((double)ang + 360.0);
@@ -1493,7 +1505,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
     // ---- phase B (second half): one cos / sin per lane ----
     const double rad = (double)angle * (ORB_PI / 180.0);
-    const double c = cos(rad), s = sin(rad);
+    double c, s;
+    if (rad >= 0.0 && rad <= 6.5) {          // every angle this library computes; a caller's angle may be anything
+        orbtrig::sincos_turn(rad, s, c, trig_table());
+    } else {
+        c = cos(rad);
+        s = sin(rad);
+    }
     const int c_lo = __double2loint(c), c_hi = __double2hiint(c);
     const int s_lo = __double2loint(s), s_hi = __double2hiint(s);
 
@@ -1732,6 +1750,7 @@ struct DescribeTileLds {
     // the last load step writes whole waves: up to 256 * DT_STEPS - DT_UNITS units past the tile, into cs,
     // which holds nothing yet at that time
     double2 cs[DT_BATCH];                            // moments, then (cos, sin)
+    double2 bxy[DT_BATCH];                           // biases of the fixed-grid rotation (x, y), see describe_tile_body
     uint32_t lst_xy[DT_LCAP];                        // (row in tile << 16) | column in tile
     int32_t lst_idx[DT_LCAP];                        // keypoint index in the frame; later its descriptor slot
     int lst_count;
@@ -1812,6 +1831,28 @@ __device__ __forceinline__ void describe_tile_body(
     __syncthreads();
     int aud_mid = 0, aud_dec = 0;            // parity audit: this lane's coordinates near a float midpoint / decisive
 
+    // Fixed-grid rotation (the common case of the descriptor rounds).  The reference's sample coordinate is
+    // RNE(fl32(c + fl32(d))) with d = fl64(fl64(px*cos) - fl64(py*sin)) (src/orb.cpp:195-206).  For S = c + px*cos
+    // - py*sin in exact arithmetic, fl32(c + fl32(d)) lies within e = 2^(E-25) + 2^-20 + 2^-45 of S when every
+    // such sum of this tile is below 2^E (half an ulp of the float sum, half an ulp of the narrowed d < 32, the
+    // three double roundings).  So when S is farther than e from every half-integer, the reference's pixel is
+    // round(S) whatever the intermediate roundings did.  Two dependent v_fma_f64 on top of the bias
+    // 1.5 * 2^36 + (c - tile origin) + 1/2 + zs * 2^-16 leave S' = S + delta, |delta| <= 2^-16, on a grid of 2^-16
+    // in the low dword of the result: high half = floor(S' + 1/2 + zs * 2^-16) in tile coordinates, low half = the
+    // fraction.  A fraction below 2 zs + 1 means S' is within zs grid steps of a half-integer; otherwise S is at
+    // least zs * 2^-16 > e away from it and the high half is the reference's pixel.  zs = 2^(E-9) + 1.  Rounds
+    // with a flagged coordinate in any lane are redone with the reference's own arithmetic (about one
+    // coordinate in 8 000).
+    int coord_max = X0 + DT_W + 21;
+    {
+        const int ymax = (band + 1) * DT_H + 21;
+        coord_max = coord_max > ymax ? coord_max : ymax;
+    }
+    const int ebits = 32 - __builtin_clz((unsigned)coord_max);           // every float sum of this tile is < 2^ebits
+    const int zs = (1 << (ebits > 9 ? ebits - 9 : 0)) + 1;
+    const uint32_t zone = 2u * (uint32_t)zs + 1u;
+    const double bias0 = 103079215104.0 + 0.5 + (double)zs * (1.0 / 65536.0);      // 1.5 * 2^36 + ...
+
     for (int s0 = k0; s0 < k1; s0 += DT_SEG) {
         // ---- gather: entries of the band's range whose column falls into this tile ----
         const int2 p = pnext;
@@ -1885,9 +1926,11 @@ __device__ __forceinline__ void describe_tile_body(
                     if (slot >= 0) {
                         const double rad = (double)angle * (ORB_PI / 180.0);
                         double2 v;
-                        v.x = cos(rad);
-                        v.y = sin(rad);
+                        orbtrig::sincos_turn(rad, v.y, v.x, trig_table());
                         cs[t] = v;
+                        v.x = bias0 + (double)(int)(pxy & 0xFFFFu);
+                        v.y = bias0 + (double)(int)(pxy >> 16);
+                        L.bxy[t] = v;
                     }
                 }
                 __syncthreads();
@@ -1901,6 +1944,48 @@ __device__ __forceinline__ void describe_tile_body(
                     float cx = (float)((int)(pxy & 0xFFFFu) + tx0), cy = (float)((int)(pxy >> 16) + ty0);
                     const float mx = RND_MAGIC - (float)tx0, my = RND_MAGIC - (float)ty0;
                     const uint32_t pitch = DT_PITCH;
+                    int v1[4], v2[4];
+                    if (!AUDIT) {
+                        const double2 bv = L.bxy[e];
+                        uint32_t ia = 0, ib = 0, mn[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t ax = (uint32_t)__double2loint(__builtin_fma(dpx1[r], cj, __builtin_fma(-dpy1[r], sn, bv.x)));
+                            const uint32_t ay = (uint32_t)__double2loint(__builtin_fma(dpx1[r], sn, __builtin_fma(dpy1[r], cj, bv.y)));
+                            const uint32_t bx = (uint32_t)__double2loint(__builtin_fma(dpx2[r], cj, __builtin_fma(-dpy2[r], sn, bv.x)));
+                            const uint32_t by = (uint32_t)__double2loint(__builtin_fma(dpx2[r], sn, __builtin_fma(dpy2[r], cj, bv.y)));
+                            // byte index = high half of y * pitch + high half of x; the destination's high half is
+                            // kept by this instruction (zero from the start), so ia / ib are chained
+                            asm("v_mad_u16 %0, %1, %2, %3 op_sel:[1,0,1,0]" : "+v"(ia) : "v"(ay), "s"(pitch), "v"(ax));
+                            v1[r] = pb[ia];
+                            asm("v_mad_u16 %0, %1, %2, %3 op_sel:[1,0,1,0]" : "+v"(ib) : "v"(by), "s"(pitch), "v"(bx));
+                            v2[r] = pb[ib];
+                            uint32_t m;
+                            asm("v_min3_u16 %0, %1, %2, %3" : "=v"(m) : "v"(ax), "v"(ay), "v"(bx));
+                            asm("v_min_u16 %0, %1, %2" : "=v"(mn[r]) : "v"(m), "v"(by));
+                        }
+                        uint32_t mall;
+                        asm("v_min3_u16 %0, %1, %2, %3" : "=v"(mall) : "v"(mn[0]), "v"(mn[1]), "v"(mn[2]));
+                        asm("v_min_u16 %0, %1, %2" : "=v"(mall) : "v"(mall), "v"(mn[3]));
+                        if (__ballot((mall & 0xFFFFu) < zone) != 0ull) {        // (uniform) rare: the reference's own chain
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                if (__ballot((mn[r] & 0xFFFFu) < zone) == 0ull) continue;
+                                const double vx1 = dpx1[r] * cj - dpy1[r] * sn, vy1 = dpx1[r] * sn + dpy1[r] * cj;
+                                const double vx2 = dpx2[r] * cj - dpy2[r] * sn, vy2 = dpx2[r] * sn + dpy2[r] * cj;
+                                const float x1r = (float)vx1, y1r = (float)vy1, x2r = (float)vx2, y2r = (float)vy2;
+                                const uint32_t ax = __float_as_uint((cx + x1r) + mx);
+                                const uint32_t ay = __float_as_uint((cy + y1r) + my);
+                                const uint32_t bx = __float_as_uint((cx + x2r) + mx);
+                                const uint32_t by = __float_as_uint((cy + y2r) + my);
+                                uint32_t j1, j2;
+                                asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(j1) : "v"(ay), "s"(pitch), "v"(ax));
+                                asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(j2) : "v"(by), "s"(pitch), "v"(bx));
+                                v1[r] = pb[j1];
+                                v2[r] = pb[j2];
+                            }
+                        }
+                    } else {
                     uint32_t i1[4], i2[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1920,9 +2005,9 @@ __device__ __forceinline__ void describe_tile_body(
                         asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i1[r]) : "v"(ay), "s"(pitch), "v"(ax));
                         asm("v_mad_legacy_u16 %0, %1, %2, %3" : "=v"(i2[r]) : "v"(by), "s"(pitch), "v"(bx));
                     }
-                    int v1[4], v2[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v1[r] = pb[i1[r]]; v2[r] = pb[i2[r]]; }
+                    }
                     unsigned long long bal[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bal[r] = __ballot(v1[r] < v2[r]);
