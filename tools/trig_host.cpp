@@ -12,7 +12,7 @@ void trig_atan2_deg(const int32_t* m01, const int32_t* m10, long n, double* deg,
 {
     for (long i = 0; i < n; ++i) {
         bool u;
-        deg[i] = orbtrig::atan2_deg_moments(m01[i], m10[i], u, orbtrig::COEF);
+        deg[i] = orbtrig::atan2_deg_moments(m01[i], m10[i], u, orbtrig::COEF, orbtrig::COEF + orbtrig::K_ATAN_QUARTER);
         unsure[i] = u;
     }
 }
@@ -54,7 +54,7 @@ void trig_angle_floats(const int32_t* m01, const int32_t* m10, long n, uint32_t*
 {
     for (long i = 0; i < n; ++i) {
         bool u;
-        double deg = orbtrig::atan2_deg_moments(m01[i], m10[i], u, orbtrig::COEF);
+        double deg = orbtrig::atan2_deg_moments(m01[i], m10[i], u, orbtrig::COEF, orbtrig::COEF + orbtrig::K_ATAN_QUARTER);
         const double ref = atan2((double)m01[i], (double)m10[i]) * (180.0 / orbtrig::PI);
         if (u) deg = ref;
         float a = (float)deg, r = (float)ref;

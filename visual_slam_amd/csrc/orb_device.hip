@@ -1155,16 +1155,18 @@ __device__ __forceinline__ TrigTable trig_table()
     return k;
 }
 
-__device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01, bool* near_midpoint = nullptr)
+template <class QuarterTable>
+__device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01, TrigTable K, QuarterTable Q,
+                                                    bool* near_midpoint = nullptr)
 {
-    if (near_midpoint) *near_midpoint = false;
-    if (m00 == 0) return 0.0f;
+    // straight-line: an all-zero patch has m10 = m01 = 0, for which the series returns 0 like atan2(0, 0)
     bool unsure;
-    const double deg = orbtrig::atan2_deg_moments(m01, m10, unsure, trig_table());
-    if (near_midpoint) *near_midpoint = near_float_midpoint(deg);
+    const double deg = orbtrig::atan2_deg_moments(m01, m10, unsure, K, Q);
+    if (near_midpoint) *near_midpoint = m00 != 0 && near_float_midpoint(deg);
     float ang = (float)deg;
-    if (ang < 0) ang = (float)((double)ang + 360.0);
-    return ang;
+    const float wrapped = (float)((double)ang + 360.0);
+    ang = ang < 0 ? wrapped : ang;
+    return m00 == 0 ? 0.0f : ang;
 }
 
 // Sum over the 64 lanes with DPP adds; the total lands in lane 63 and is returned wave-uniform.
@@ -1414,10 +1416,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     __shared__ int bucket_count[256];
     __shared__ int wave_sum_lds[4];
     __shared__ uint16_t order[256];
+    __shared__ double atan_quarter_lds[8];    // atan(k / 4), k = 0 .. 4: looked up per lane (written before the barriers below)
     int kidx = -1;                            // this lane's keypoint, relative to wg_base
     {
         const int t = threadIdx.x;
         bucket_count[t] = 0;
+        if (t < 5) atan_quarter_lds[t] = orbtrig::COEF[orbtrig::K_ATAN_QUARTER + t];
         __syncthreads();
         const int shift = W > 256 ? 32 - __builtin_clz((unsigned)(W - 1)) - 8 : 0;
         int bkt = 0, rank = 0;
@@ -1484,10 +1488,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // ---- phase B (first half): one atan2 per lane ----
         if (AUDIT) {
             bool near;
-            angle = angle_from_moments(m00, m10, m01, &near);
+            angle = angle_from_moments(m00, m10, m01, trig_table(), atan_quarter_lds, &near);
             if (mine && near) atomicAdd(&risk[4 * f], 1);
         } else {
-            angle = angle_from_moments(m00, m10, m01);
+            angle = angle_from_moments(m00, m10, m01, trig_table(), atan_quarter_lds);
         }
     }
     if (mine) {
@@ -1740,7 +1744,7 @@ constexpr int DT_UNITS = DT_ROWS * DT_PITCH_Q;       // 2033
 constexpr int DT_STEPS = (DT_UNITS + 255) / 256;     // tile load steps of 256 units (one per thread)
 constexpr int DT_SEG = 256;                          // list entries scanned per pass (one per thread)
 constexpr int DT_LCAP = 384;                         // keypoints gathered before they are processed
-constexpr int DT_BATCH = 128;                        // keypoints per moments / trigonometry / descriptor round
+constexpr int DT_BATCH = 64;                         // keypoints per moments / trigonometry / descriptor round: one wave's lanes
 static_assert(DT_W % 16 == 0 && DT_MX % 16 == 0 && DT_MY % 2 == 0 && DT_MX >= 22 && DT_MY >= 21, "halo, even origin, aligned units");
 static_assert(DT_ROWS * DT_PITCH < 65536, "LDS byte index fits 16 bits");
 static_assert(256 == 13 * DT_PITCH_Q + 9, "tile walk: 256 units on = 13 rows and 9 units");
@@ -1752,7 +1756,9 @@ struct DescribeTileLds {
     double2 cs[DT_BATCH];                            // moments, then (cos, sin)
     double2 bxy[DT_BATCH];                           // biases of the fixed-grid rotation (x, y), see describe_tile_body
     uint32_t lst_xy[DT_LCAP];                        // (row in tile << 16) | column in tile
-    int32_t lst_idx[DT_LCAP];                        // keypoint index in the frame; later its descriptor slot
+    int32_t lst_idx[DT_LCAP];                        // keypoint index in the frame
+    int32_t lst_slot[DT_LCAP];                       // its descriptor row, or -1 (fetched with the list entry)
+    double atan_quarter[8];                          // atan(k / 4), k = 0 .. 4: looked up per lane
     int lst_count;
 };
 static_assert((256 * DT_STEPS - DT_UNITS) * 16 <= (int)sizeof(double2) * DT_BATCH, "load overrun stays inside cs");
@@ -1792,7 +1798,8 @@ __device__ __forceinline__ void describe_tile_body(
 
     // first pass of the list scan: in flight together with the tile
     int2 pnext = make_int2(-1, -1);
-    if (k0 + t < k1) pnext = kpxy[kf + k0 + t];
+    int snext = -1;
+    if (k0 + t < k1) { pnext = kpxy[kf + k0 + t]; snext = kpslot[kf + k0 + t]; }
 
     // ---- the tile: rows ty0 .. ty0 + 106, columns tx0 .. tx0 + 303, straight into LDS in 16-byte units.
     // Bounds-checked buffer loads return zero past either end of the frame (rows above and below the image);
@@ -1815,6 +1822,7 @@ __device__ __forceinline__ void describe_tile_body(
         }
     }
     if (t == 0) L.lst_count = 0;
+    if (t < 5) L.atan_quarter[t] = orbtrig::COEF[orbtrig::K_ATAN_QUARTER + t];
 
     // this lane's four test pairs, as doubles.  (A rotation table in LDS, as the per-keypoint kernel keeps,
     // would cost 16 KB of LDS reads per keypoint: with the image tile in LDS as well, that is the limit.)
@@ -1856,12 +1864,14 @@ __device__ __forceinline__ void describe_tile_body(
     for (int s0 = k0; s0 < k1; s0 += DT_SEG) {
         // ---- gather: entries of the band's range whose column falls into this tile ----
         const int2 p = pnext;
+        const int pslot = snext;
         pnext = make_int2(-1, -1);
-        if (s0 + DT_SEG + t < k1) pnext = kpxy[kf + s0 + DT_SEG + t];
+        if (s0 + DT_SEG + t < k1) { pnext = kpxy[kf + s0 + DT_SEG + t]; snext = kpslot[kf + s0 + DT_SEG + t]; }
         if (p.x >= X0 && p.x < X0 + DT_W) {
             const int pos = atomicAdd(&L.lst_count, 1);
             lst_xy[pos] = ((uint32_t)(p.y - ty0) << 16) | (uint32_t)(p.x - tx0);
             lst_idx[pos] = s0 + t;
+            L.lst_slot[pos] = pslot;
         }
         __syncthreads();
         const int cnt = L.lst_count;
@@ -1904,39 +1914,39 @@ __device__ __forceinline__ void describe_tile_body(
                     }
                 }
                 __syncthreads();
-                // ---- one keypoint per thread: angle, keypoint row, cos / sin ----
+                // ---- one keypoint per lane of the first wave: angle, keypoint row, cos / sin.  Straight-line code
+                // with nothing to wait for but LDS: the descriptor slot came in with the list entry. ----
                 if (t < nb) {
                     const int* m = reinterpret_cast<const int*>(&cs[t]);
+                    const int m00 = m[0], m10 = m[1], m01 = m[2];
+                    const uint32_t pxy = lst_xy[bb + t];
+                    const int i = lst_idx[bb + t];
+                    const int slot = L.lst_slot[bb + t];
+                    const TrigTable K = trig_table();
                     float angle;
                     if (AUDIT) {
                         bool near;
-                        angle = angle_from_moments(m[0], m[1], m[2], &near);
+                        angle = angle_from_moments(m00, m10, m01, K, L.atan_quarter, &near);
                         if (near) atomicAdd(&risk[4 * f], 1);
                     } else {
-                        angle = angle_from_moments(m[0], m[1], m[2]);
+                        angle = angle_from_moments(m00, m10, m01, K, L.atan_quarter);
                     }
-                    const uint32_t pxy = lst_xy[bb + t];
-                    const int i = lst_idx[bb + t];
                     float* row = kp7 + (kf + i) * 7;
                     row[0] = (float)((int)(pxy & 0xFFFFu) + tx0); row[1] = (float)((int)(pxy >> 16) + ty0);
                     row[2] = 7.0f; row[3] = angle; row[4] = 0.0f; row[5] = 0.0f; row[6] = -1.0f;
-                    const int slot = kpslot[kf + i];
                     if (slot >= 0 && valid_idx) valid_idx[kf + slot] = i;
-                    lst_idx[bb + t] = slot;
-                    if (slot >= 0) {
-                        const double rad = (double)angle * (ORB_PI / 180.0);
-                        double2 v;
-                        orbtrig::sincos_turn(rad, v.y, v.x, trig_table());
-                        cs[t] = v;
-                        v.x = bias0 + (double)(int)(pxy & 0xFFFFu);
-                        v.y = bias0 + (double)(int)(pxy >> 16);
-                        L.bxy[t] = v;
-                    }
+                    const double rad = (double)angle * (ORB_PI / 180.0);
+                    double2 v;
+                    orbtrig::sincos_turn(rad, v.y, v.x, K);
+                    cs[t] = v;
+                    v.x = bias0 + (double)(int)(pxy & 0xFFFFu);
+                    v.y = bias0 + (double)(int)(pxy >> 16);
+                    L.bxy[t] = v;
                 }
                 __syncthreads();
                 // ---- descriptors: the waves take the keypoints of the batch in turn ----
                 for (int e = wave; e < nb; e += 4) {
-                    const int slot = __builtin_amdgcn_readfirstlane(lst_idx[bb + e]);
+                    const int slot = __builtin_amdgcn_readfirstlane(L.lst_slot[bb + e]);
                     if (slot < 0) continue;
                     const uint32_t pxy = lst_xy[bb + e];
                     const double2 csv = cs[e];

@@ -58,8 +58,9 @@ double COEF[K_COUNT] = {
 
 // atan2(m01, m10) * (180 / pi) for integers |m| < 2^22, as a double before the narrowing to float.
 // Straight-line code: every lane of a wave takes the same path.
-template <class Table>
-ORB_TRIG_FN double atan2_deg_moments(int m01, int m10, bool& unsure, Table K)
+// Q[k] = atan(k / 4), indexed per lane (a device caller keeps these five in LDS).
+template <class Table, class QuarterTable>
+ORB_TRIG_FN double atan2_deg_moments(int m01, int m10, bool& unsure, Table K, QuarterTable Q)
 {
     const int ax = m10 < 0 ? -m10 : m10, ay = m01 < 0 ? -m01 : m01;
     const bool swap = ay > ax;
@@ -76,10 +77,7 @@ ORB_TRIG_FN double atan2_deg_moments(int m01, int m10, bool& unsure, Table K)
     double p = K[K_ATAN_SERIES];
 #pragma unroll
     for (int i = 1; i < 8; ++i) p = __builtin_fma(p, z, K[K_ATAN_SERIES + i]);
-    const double q0 = K[K_ATAN_QUARTER], q1 = K[K_ATAN_QUARTER + 1], q2 = K[K_ATAN_QUARTER + 2],
-                 q3 = K[K_ATAN_QUARTER + 3], q4 = K[K_ATAN_QUARTER + 4];
-    const double qa = k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : k == 3 ? q3 : q4;
-    const double a = qa + __builtin_fma(t, z * p, t);
+    const double a = Q[k] + __builtin_fma(t, z * p, t);
     // a -> pi/2 - a (moments swapped), then -> pi - a (m10 < 0), each with the constant's own rounding error
     // added back
     const double a1 = swap ? (PIO2 - a) + PIO2_LO : a;
