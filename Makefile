@@ -28,7 +28,7 @@ oracle:
 	$(MAKE) -s -C oracle
 
 # Stand-alone measurement programs (not part of the library).
-MICRO := build/stream_read build/valu_rates build/valu_peak build/mfma_fp4_probe build/mfma_valu_coexec build/mfma_top2_pattern build/coexec_classes build/mfma_port_block
+MICRO := build/stream_read build/valu_rates build/valu_peak build/mfma_fp4_probe build/mfma_valu_coexec build/mfma_top2_pattern build/coexec_classes build/mfma_port_block build/wave_simd_map
 micro: $(MICRO)
 build/%: $(CSRC)/micro/%.hip
 	mkdir -p build
