@@ -14,7 +14,7 @@ PYINC      := $(shell $(PYTHON) -m pybind11 --includes)
 LIB    := visual_slam_amd/liborbamd.so
 MODULE := build/orb_project$(EXT_SUFFIX)
 
-all: $(LIB) $(MODULE) oracle
+all: $(LIB) $(MODULE) oracle trighost
 
 $(LIB): $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip $(CSRC)/orb_internal.h $(CSRC)/orb_pattern.h $(CSRC)/orb_trig.h include/orbamd.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/orb_device.hip $(CSRC)/orb_capi.hip
@@ -27,6 +27,13 @@ $(MODULE): $(CSRC)/orb_module.cpp include/orbamd.h $(LIB)
 oracle:
 	$(MAKE) -s -C oracle
 
+# Host build of csrc/orb_trig.h for tests/test_trig_kernels.py (test infrastructure; needs a CPU with FMA, which
+# the test checks before loading it).
+trighost: build/libtrig_host.so
+build/libtrig_host.so: tests/trig_host.cpp $(CSRC)/orb_trig.h
+	mkdir -p build
+	$(CXX) -O2 -mfma -ffp-contract=off -shared -fPIC -o $@ tests/trig_host.cpp -lm
+
 # Stand-alone measurement programs (not part of the library).
 MICRO := build/stream_read build/valu_rates build/valu_peak build/mfma_fp4_probe build/mfma_valu_coexec build/mfma_top2_pattern build/coexec_classes build/mfma_port_block build/wave_simd_map
 micro: $(MICRO)
@@ -37,4 +44,4 @@ build/%: $(CSRC)/micro/%.hip
 clean:
 	rm -f $(LIB) $(MODULE) oracle/liborb_oracle.so oracle/liborb_oracle_O0.so
 
-.PHONY: all oracle micro clean
+.PHONY: all oracle micro clean trighost

@@ -315,6 +315,17 @@ int orbamd_knn2_dev(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* 
 int orbamd_knn2_dev_noalloc(orbamd_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                             int32_t* d_idx, int32_t* d_dist, uint8_t* d_good);
 
+/* Test hook, no counterpart in the reference: the library's own arc tangent / sine / cosine (what the
+ * orientation step uses in place of the libm calls of reference src/orb.cpp:127 and :173-174), evaluated
+ * element-wise on the device, so that a test can compare them bit for bit with a host build of the same source
+ * (csrc/orb_trig.h) and so carry the host-side accuracy measurements over to the device.
+ *   d_deg[i]    = atan2(d_m01[i], d_m10[i]) * (180 / pi) as a double, i < n (|moments| < 2^22)
+ *   d_unsure[i] = 1 when that double is within 2^-43 (relative) of a float rounding midpoint
+ *   d_sin[j], d_cos[j] of d_rad[j], j < m (0 <= d_rad[j] <= 6.5)
+ * Device pointers; asynchronous on the context's stream. */
+int orbamd_trig_selftest_dev(orbamd_ctx* ctx, const int32_t* d_m01, const int32_t* d_m10, int n, double* d_deg,
+                             uint8_t* d_unsure, const double* d_rad, int m, double* d_sin, double* d_cos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 so = os.path.join(ROOT, "build", "libtrig_host.so")
 subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-shared", "-fPIC", "-o", so,
-                       os.path.join(ROOT, "tools", "trig_host.cpp"), "-lm"])
+                       os.path.join(ROOT, "tests", "trig_host.cpp"), "-lm"])
 L = ctypes.CDLL(so)
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hi = int(np.float32(360.0).view(np.uint32)) + 1

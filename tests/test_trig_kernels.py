@@ -1,5 +1,5 @@
 """The purpose-built arc tangent / sine / cosine of the orientation step (visual_slam_amd/csrc/orb_trig.h), run on
-the host (no GPU): the header is plain C++ with __builtin_fma, tools/trig_host.cpp wraps it, and g++ -mfma gives the
+the host (no GPU): the header is plain C++ with __builtin_fma, tests/trig_host.cpp wraps it, and g++ -mfma gives the
 arithmetic the device executes.  What the kernels rely on:
 
 * atan2_deg_moments: relative error of a few units in the last place, far inside the 2^-43 window its `unsure`
@@ -30,7 +30,7 @@ def trig():
     if not _has_fma():
         pytest.skip("host CPU has no FMA instruction")
     so = os.path.join(ROOT, "build", "libtrig_host.so")
-    src = os.path.join(ROOT, "tools", "trig_host.cpp")
+    src = os.path.join(ROOT, "tests", "trig_host.cpp")
     hdr = os.path.join(ROOT, "visual_slam_amd", "csrc", "orb_trig.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         os.makedirs(os.path.dirname(so), exist_ok=True)
@@ -127,3 +127,41 @@ def test_sincos_against_host_libm_on_a_dense_range(trig):
     n, ds, dc, worst = list(out)
     assert n == 4_000_000 and worst <= 1
     assert ds < 0.05 * n and dc < 0.05 * n
+
+
+@pytest.mark.gpu
+def test_device_trigonometry_is_the_host_build_bit_for_bit(trig, gctx):
+    """The same header on the device (through the library's test hook) and on the host: identical doubles, so what
+    the host-side tests and scripts/trig_exhaustive.py establish holds for the kernels."""
+    import torch
+    n = 2_000_000
+    m01, m10 = _moments(n, 23)
+    rng = np.random.default_rng(29)
+    ang = np.concatenate([rng.uniform(0, 360, n - 400), np.arange(0, 361, dtype=np.float64),
+                          np.nextafter(np.float32([90, 180, 270, 360]), np.float32(0)).astype(np.float64),
+                          rng.uniform(0, 1e-3, 35)]).astype(np.float32)
+    rad = ang.astype(np.float64) * (PI / 180.0)
+    m = rad.size
+    deg_h = np.empty(n)
+    uns_h = np.empty(n, np.uint8)
+    trig.trig_atan2_deg(_p(m01, ctypes.c_int32), _p(m10, ctypes.c_int32), ctypes.c_long(n), _p(deg_h, ctypes.c_double),
+                        _p(uns_h, ctypes.c_uint8))
+    s_h = np.empty(m)
+    c_h = np.empty(m)
+    trig.trig_sincos(_p(rad, ctypes.c_double), ctypes.c_long(m), _p(s_h, ctypes.c_double), _p(c_h, ctypes.c_double))
+    dev = torch.device("cuda:0")
+    d01 = torch.from_numpy(m01).to(dev)
+    d10 = torch.from_numpy(m10).to(dev)
+    drad = torch.from_numpy(rad).to(dev)
+    ddeg = torch.empty(n, dtype=torch.float64, device=dev)
+    duns = torch.empty(n, dtype=torch.uint8, device=dev)
+    dsin = torch.empty(m, dtype=torch.float64, device=dev)
+    dcos = torch.empty(m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    gctx.trig_selftest_dev(d01.data_ptr(), d10.data_ptr(), n, ddeg.data_ptr(), duns.data_ptr(), drad.data_ptr(), m,
+                           dsin.data_ptr(), dcos.data_ptr())
+    gctx.sync()
+    assert np.array_equal(ddeg.cpu().numpy().view(np.uint64), deg_h.view(np.uint64))
+    assert np.array_equal(duns.cpu().numpy(), uns_h)
+    assert np.array_equal(dsin.cpu().numpy().view(np.uint64), s_h.view(np.uint64))
+    assert np.array_equal(dcos.cpu().numpy().view(np.uint64), c_h.view(np.uint64))

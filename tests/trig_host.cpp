@@ -1,6 +1,6 @@
 // Host build of csrc/orb_trig.h for tests/test_trig_kernels.py and scripts/trig_exhaustive.py (test
 // infrastructure: the product only ever runs these functions on the device).
-//   g++ -O2 -mfma -ffp-contract=off -shared -fPIC -o build/libtrig_host.so tools/trig_host.cpp -lm
+//   g++ -O2 -mfma -ffp-contract=off -shared -fPIC -o build/libtrig_host.so tests/trig_host.cpp -lm
 #include <math.h>
 #include <stdint.h>
 #include <string.h>

@@ -65,6 +65,7 @@ SIGNATURES = {
     "orbamd_knn2_cross_dev": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "orbamd_knn2_dev": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp]),
     "orbamd_knn2_dev_noalloc": (_int, [_c_ctx, _vp, _int, _vp, _int, _vp, _vp, _vp]),
+    "orbamd_trig_selftest_dev": (_int, [_c_ctx, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp]),
 }
 
 _lib = None
@@ -369,6 +370,12 @@ class Context:
     def knn2_dev(self, d_q, nq, d_t, nt, d_idx, d_dist, d_good=0):
         self._chk(lib().orbamd_knn2_dev(self._h, _vp(d_q), nq, _vp(d_t or 0), nt, _vp(d_idx), _vp(d_dist),
                                         _vp(d_good or 0)), "knn2_dev")
+
+    def trig_selftest_dev(self, d_m01, d_m10, n, d_deg, d_unsure, d_rad, m, d_sin, d_cos):
+        """Test hook: the orientation step's own atan2 / sincos, element-wise on the device."""
+        self._chk(lib().orbamd_trig_selftest_dev(self._h, _vp(d_m01 or 0), _vp(d_m10 or 0), n, _vp(d_deg or 0),
+                                                 _vp(d_unsure or 0), _vp(d_rad or 0), m, _vp(d_sin or 0),
+                                                 _vp(d_cos or 0)), "trig_selftest_dev")
 
     def knn2_dev_noalloc(self, d_q, nq, d_t, nt, d_idx, d_dist, d_good=0):
         """knn2_dev on the library's fixed scratch array: no allocation, nq <= NOALLOC_MAX_QUERIES."""

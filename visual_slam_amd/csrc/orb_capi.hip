@@ -1076,6 +1076,17 @@ int orbamd_synth_textured_dev(orbamd_ctx* c, uint8_t* d_gray, int frames, int H,
     return post_launch(c, "synth_kernel");
 }
 
+int orbamd_trig_selftest_dev(orbamd_ctx* c, const int32_t* d_m01, const int32_t* d_m10, int n, double* d_deg,
+                             uint8_t* d_unsure, const double* d_rad, int m, double* d_sin, double* d_cos)
+{
+    CHK(enter(c));
+    if (n < 0 || m < 0 || (n > 0 && (!d_m01 || !d_m10 || !d_deg || !d_unsure)) || (m > 0 && (!d_rad || !d_sin || !d_cos)))
+        return ORBAMD_E_BADARG;
+    if (n == 0 && m == 0) return ORBAMD_OK;
+    launch_trig_selftest(d_m01, d_m10, n, d_deg, d_unsure, d_rad, m, d_sin, d_cos, c->stream);
+    return post_launch(c, "trig_selftest_kernel");
+}
+
 int orbamd_bgr2gray_dev(orbamd_ctx* c, const uint8_t* d_bgr, int frames, int H, int W, uint8_t* d_gray)
 {
     CHK(enter(c));

@@ -1169,6 +1169,39 @@ __device__ __forceinline__ float angle_from_moments(int m00, int m10, int m01, T
     return m00 == 0 ? 0.0f : ang;
 }
 
+// Test hook: the two functions of orb_trig.h as the kernels call them (coefficient table through the opaque
+// pointer, quarter table in LDS), one element per thread.
+__global__ __launch_bounds__(256) void trig_selftest_kernel(const int32_t* __restrict__ m01, const int32_t* __restrict__ m10,
+                                                            int n, double* __restrict__ deg, uint8_t* __restrict__ unsure,
+                                                            const double* __restrict__ rad, int m,
+                                                            double* __restrict__ sn, double* __restrict__ cs)
+{
+    __shared__ double quarter[8];
+    if (threadIdx.x < 5) quarter[threadIdx.x] = orbtrig::COEF[orbtrig::K_ATAN_QUARTER + threadIdx.x];
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const TrigTable K = trig_table();
+    if (i < n) {
+        bool u;
+        deg[i] = orbtrig::atan2_deg_moments(m01[i], m10[i], u, K, quarter);
+        unsure[i] = u;
+    }
+    if (i < m) {
+        double s, c;
+        orbtrig::sincos_turn(rad[i], s, c, K);
+        sn[i] = s;
+        cs[i] = c;
+    }
+}
+
+void launch_trig_selftest(const int32_t* m01, const int32_t* m10, int n, double* deg, uint8_t* unsure,
+                          const double* rad, int m, double* sn, double* cs, hipStream_t s)
+{
+    const int big = n > m ? n : m;
+    hipLaunchKernelGGL(trig_selftest_kernel, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, s, m01, m10, n, deg, unsure,
+                       rad, m, sn, cs);
+}
+
 // Sum over the 64 lanes with DPP adds; the total lands in lane 63 and is returned wave-uniform.
 __device__ __forceinline__ int wave_total(int v)
 {

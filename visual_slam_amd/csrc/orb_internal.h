@@ -92,6 +92,9 @@ struct Knn2Args {
 };
 // Descriptor rows (rank among keypoints >= 16 px from every edge) for a caller-supplied list;
 // counts[0] = n, counts[1] = number of descriptor rows.
+// Test hook: orb_trig.h on the device, element-wise.
+void launch_trig_selftest(const int32_t* m01, const int32_t* m10, int n, double* deg, uint8_t* unsure,
+                          const double* rad, int m, double* sn, double* cs, hipStream_t s);
 void launch_slots(const int2* kpxy, int n, int H, int W, int32_t* kpslot, int32_t* counts, hipStream_t s);
 // Ordered compaction of the ratio test over one query set; count[0] = kept rows, or -1 when a
 // query has fewer than two neighbours.
