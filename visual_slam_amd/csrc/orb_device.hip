@@ -32,6 +32,17 @@ namespace orbamd {
 
 // Pair-major sampling pattern in constant memory: bytes 4k .. 4k+3 = {x1, y1, x2, y2} of pair k.
 __constant__ __attribute__((aligned(16))) int8_t c_pairs[ORBAMD_PATTERN_PAIRS * 4] = ORBAMD_PATTERN_QUADS_INIT;
+// The same table as doubles (built at compile time): a lane's four operands of a round are 32 contiguous bytes,
+// fetched by two loads instead of being unpacked and converted by a dozen vector instructions.
+struct PairsAsDoubles { double v[ORBAMD_PATTERN_PAIRS * 4]; };
+constexpr PairsAsDoubles pairs_as_doubles()
+{
+    constexpr int8_t q[ORBAMD_PATTERN_PAIRS * 4] = ORBAMD_PATTERN_QUADS_INIT;
+    PairsAsDoubles t{};
+    for (int i = 0; i < ORBAMD_PATTERN_PAIRS * 4; ++i) t.v[i] = (double)q[i];
+    return t;
+}
+__constant__ __attribute__((aligned(32))) PairsAsDoubles c_pairs_d = pairs_as_doubles();
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -1845,7 +1856,7 @@ __device__ __forceinline__ void describe_tile_body(
         int off = (ty0 + row) * W + gx;
 #pragma unroll
         for (int k = 0; k < DT_STEPS; ++k) {
-            const bool ok = gx >= 0 && gx < W && (k + 1 < DT_STEPS || t + 256 * k < DT_UNITS);
+            const bool ok = (uint32_t)gx < (uint32_t)W && (k + 1 < DT_STEPS || t + 256 * k < DT_UNITS);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsrc, (__attribute__((address_space(3))) void*)(tile32 + 4 * (256 * k + 64 * wave)), 16,
                 ok ? (uint32_t)off : 0x80000000u, 0, 0, 0);
@@ -1862,11 +1873,9 @@ __device__ __forceinline__ void describe_tile_body(
     double dpx1[4], dpy1[4], dpx2[4], dpy2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const uint32_t q = reinterpret_cast<const uint32_t*>(c_pairs)[64 * r + lane];
-        dpx1[r] = (double)(int8_t)(q & 255u);
-        dpy1[r] = (double)(int8_t)((q >> 8) & 255u);
-        dpx2[r] = (double)(int8_t)((q >> 16) & 255u);
-        dpy2[r] = (double)(int8_t)(q >> 24);
+        const double2* pd = reinterpret_cast<const double2*>(c_pairs_d.v) + 2 * (64 * r + lane);
+        const double2 a = pd[0], b = pd[1];
+        dpx1[r] = a.x; dpy1[r] = a.y; dpx2[r] = b.x; dpy2[r] = b.y;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
