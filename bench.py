@@ -425,9 +425,12 @@ def main():
                     "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
                     "frac": rate / 1e9 / VALU_ISSUE_PEAK_GINST,
                     "per_keypoint": insts / max(1.0, float(n.sum())) if name == "orient_describe" else None}
-    # Orientation + descriptors: the reference's double -> float -> cvRound chain costs a fixed number of vector
-    # instructions per test pair, so the kernel's real bound is vector-instruction issue; the HBM figure is kept
-    # beside it.
+                if rate / 1e9 > VALU_ISSUE_PEAK_GINST:
+                    # more instructions per second than the chip can issue: the replayed count belongs to an older,
+                    # longer build of this kernel (re-run scripts/r03_profiles.sh + scripts/r03_collect.sh)
+                    rooflines[name]["valu_issue"]["stale_counter_file"] = True
+    # Orientation + descriptors: every rotated sample coordinate costs vector instructions (two double FMAs at
+    # the least), so the kernel's real bound is vector-instruction issue; the HBM figure is kept beside it.
     od = rooflines.get("orient_describe")
     if od is not None and "valu_issue" in od:
         vi = od.pop("valu_issue")
