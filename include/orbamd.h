@@ -100,9 +100,9 @@ int orbamd_ctx_set_detector(orbamd_ctx* ctx, int threshold, int arc, int wrap, i
 
 /* Parity audit, off by default; no counterpart in the reference.  The reference narrows doubles that come out
  * of libm calls to float: the angle atan2(m01, m10) * (180 / pi) (src/orb.cpp:127-129) and every rotated sample
- * coordinate x * cos - y * sin (src/orb.cpp:195-199).  The device's libm is not glibc; a difference in the last
- * bits of such a double changes the float only if the double lies next to the midpoint of two neighbouring
- * floats.  With the audit on, the orientation / descriptor kernels count exactly those cases, per frame:
+ * coordinate x * cos - y * sin (src/orb.cpp:195-199).  The device's arc tangent, sine and cosine are the
+ * library's own series, not glibc's code; a difference in the last bits of such a double changes the float
+ * only if the double lies next to the midpoint of two neighbouring floats.  With the audit on, the orientation / descriptor kernels count exactly those cases, per frame:
  *   [0] keypoints whose angle (before narrowing) is within 4 units in the last place of such a midpoint
  *   [1] sample coordinates (before narrowing) within 4 units in the last place of such a midpoint
  *   [2] those of [1] for which the two candidate floats, added to the keypoint's coordinate, also round to

@@ -71,13 +71,14 @@ def test_atan2_series_accuracy_and_narrowing(trig):
     rel = np.abs((deg.astype(np.longdouble) - ref)[nz] / ref[nz])
     assert float(rel.max()) < 2.0 ** -50, float(rel.max())
     assert unsure.sum() < 50                                # about one in 260 000 expected
-    # the stored float angle equals the one libm gives, flagged cases left out (the kernels do not: both are
-    # "a libm within an ulp" there)
+    # the stored float angle equals the one this host's libm gives wherever the flag is clear (where it is set, the
+    # two may differ: either could be the reference's float, that is what the flag means)
     mine = np.empty(n, np.uint32)
     libm = np.empty(n, np.uint32)
     trig.trig_angle_floats(_p(m01, ctypes.c_int32), _p(m10, ctypes.c_int32), ctypes.c_long(n), _p(mine, ctypes.c_uint32),
                            _p(libm, ctypes.c_uint32), _p(unsure, ctypes.c_uint8))
-    assert np.array_equal(mine, libm)
+    clear = unsure == 0
+    assert np.array_equal(mine[clear], libm[clear])
 
 
 def test_atan2_series_special_cases(trig):

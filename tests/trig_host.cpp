@@ -48,15 +48,14 @@ void trig_sincos_vs_libm(uint32_t lo_bits, uint32_t hi_bits, long* out)
     out[0] = n; out[1] = ds; out[2] = dc; out[3] = worst;
 }
 
-// The float angle the orientation step stores, from this header's arc tangent (or from libm when `unsure`),
-// and from libm alone: both as float bit patterns.
+// The float angle the orientation step stores, from this header's arc tangent and from this host's libm: both as
+// float bit patterns, with the header's `unsure` flag.
 void trig_angle_floats(const int32_t* m01, const int32_t* m10, long n, uint32_t* mine, uint32_t* libm, uint8_t* unsure)
 {
     for (long i = 0; i < n; ++i) {
         bool u;
         double deg = orbtrig::atan2_deg_moments(m01[i], m10[i], u, orbtrig::COEF, orbtrig::COEF + orbtrig::K_ATAN_QUARTER);
         const double ref = atan2((double)m01[i], (double)m10[i]) * (180.0 / orbtrig::PI);
-        if (u) deg = ref;
         float a = (float)deg, r = (float)ref;
         if (a < 0) a = (float)((double)a + 360.0);
         if (r < 0) r = (float)((double)r + 360.0);

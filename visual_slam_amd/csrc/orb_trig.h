@@ -9,8 +9,9 @@
 //    reduced with exact integer arithmetic to |t| <= 1/8 and a 9-term series; the relative error of the result
 //    is a few units in the last place.  The caller narrows the angle to float: `unsure` reports that the double
 //    lies within 2^-43 (relative) of the midpoint of two neighbouring floats, the only case in which an error of
-//    that size, or the (smaller) error of any libm, can decide the narrowing.  Such keypoints - about one in
-//    260 000 - take the libm call instead.
+//    that size, or the (smaller) error of any libm, the reference's included, can decide the narrowing - about
+//    one keypoint in 260 000.  The kernels use the series there too (a library call is no closer to the
+//    reference's libm than the series is); the flag is for audits and tests.
 //  * sincos_turn: sine and cosine of an angle in [0, 2 pi]: Cody-Waite reduction by pi/2 (exact first step,
 //    the second carries its rounding error along as a tail) and the classic degree-13 / degree-14 minimax
 //    kernels (Sun fdlibm's published coefficients) on [-pi/4, pi/4].  Error below one unit in the last place.
