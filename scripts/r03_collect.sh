@@ -1,5 +1,5 @@
 #!/bin/bash
-# After `gpurun -- bash scripts/r03_profiles.sh`: copy the summaries that README / DESIGN / bench.py cite from
+# After `gpurun -- bash scripts/r03_profiles.sh`: copy the summaries the documentation and bench.py cite from
 # gpurun_out/ (scratch) into profiles/ (tracked).   bash scripts/r03_collect.sh
 set -e
 cd "$(dirname "$0")/.."

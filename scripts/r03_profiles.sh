@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence: everything README / DESIGN quote, collected in one go on the GPU box and copied to profiles/.
+# Evidence run: every figure the documentation quotes, collected in one go on the GPU box (see r03_collect.sh).
 #   bash scripts/r03_profiles.sh      (results under gpurun_out/r03_prof/ and gpurun_out/prof_r03/, pmc_r03/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03_prof
