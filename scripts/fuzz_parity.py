@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--single", action="store_true", help="also run each case's first frame through extract_gray")
     args = ap.parse_args()
     import torch
     import oracle
@@ -64,6 +65,11 @@ def main():
         m = eng.match_consecutive(feat) if B > 1 else None
         eng.sync()
         what = []
+        if args.single:                                   # the single-frame, host-pointer call on the first frame
+            skp, sdesc, svidx = eng.ctx.extract_gray(host[0])
+            if not (skp.shape == ex[0][0].shape and np.array_equal(skp.view(np.uint32), ex[0][0].view(np.uint32))
+                    and np.array_equal(sdesc, ex[0][1]) and np.array_equal(svidx, ex[0][2])):
+                what.append("single-frame call")
         for i in range(B):
             kp, desc, vidx = feat.frame(i)
             if kp.shape != ex[i][0].shape or not np.array_equal(kp.view(np.uint32), ex[i][0].view(np.uint32)):
