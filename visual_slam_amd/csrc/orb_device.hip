@@ -689,7 +689,8 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
                                                         int aligned, int ntc, int ntr,
                                                         unsigned long long* __restrict__ rowcnt)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile32[FT_LH * FT_PITCH];                 // 20160 B
+    // (whole load steps: the last one writes zeros into the 20 segments behind the tile's 1260)
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[256 * FT_SPT * 4];                 // 20480 B
     __shared__ uint32_t mtile[FT_H * (FT_W / 32)];                // 2 KiB: the tile's corner bits
     __shared__ uint16_t lists[4][FT_LIST_A + FT_LIST_B];           // per wave: list A, then list B
     // 1-D grid, tile column fastest.  Neighbouring tiles read each other's edge cache lines (the
@@ -707,10 +708,29 @@ __global__ __launch_bounds__(256) void fast_mask_kernel(const uint8_t* __restric
     const int lane = lane_id(), wave = wave_id();
 
     if (aligned == 16) {
-        FastStage16 st;
-        const bool inside = fast_tile_inside(H, W, x0, y0);
-        fast_stage16_load(st, img, H, W, x0, y0, inside);
-        fast_stage16_store(st, tile32, H, W, x0, y0, inside);
+        // Segments straight into LDS (no registers, no LDS store instructions): segment idx of the tile lands at
+        // byte 16 * idx, which is where a wave's lanes write when the LDS base advances by 64 segments per wave
+        // and 256 per step.  Rows above / below the frame fall outside the buffer and read as zero; segments left
+        // or right of it (W is a multiple of 16: inside or outside as a whole) get an out-of-range offset.  No
+        // pixel outside the frame is ever looked at by a pixel that can be a corner.
+        constexpr int SPR = FT_PITCH / 4;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, H * W, 0x00020000);
+        const int t = (int)threadIdx.x;
+        const int row0 = t / SPR, seg0 = t - SPR * row0;
+        const int xs0 = x0 - 16 + 16 * seg0;
+        const int off0 = __mul24(y0 - 3 + row0, W) + xs0;
+#pragma unroll
+        for (int i = 0; i < FT_SPT; ++i) {
+            const int drow = (256 * i) / SPR, dseg = (256 * i) % SPR;
+            const bool wrap = seg0 + dseg >= SPR;
+            const int x = xs0 + 16 * dseg - (wrap ? 16 * SPR : 0);
+            const int off = off0 + drow * W + 16 * dseg + (wrap ? W - 16 * SPR : 0);
+            const bool ok = (uint32_t)x < (uint32_t)W && t + 256 * i < FT_SEGS;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(tile32 + 4 * (256 * i + 64 * wave)), 16,
+                ok ? (uint32_t)off : 0x80000000u, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (aligned == 4) {
         FastStage st;
         fast_stage_load(st, img, H, W, x0, y0, lane, wave);
