@@ -478,72 +478,10 @@ __device__ __forceinline__ void fast_stage_store(const FastStage& st, uint32_t* 
 // segments long, so segment idx lands at byte 16 * idx.  The halo columns ride in the same load
 // instructions as the body: fetching them with loads of their own (one dword per lane and row, 64
 // different cache lines per instruction) cost a third of the kernel's run time on MI355X.
-// Same clamp-then-zero rule as above.
+// The loads themselves are in fast_mask_kernel: bounds-checked buffer loads that write LDS directly.
 constexpr int FT_SEGS = FT_LH * (FT_PITCH / 4);          // 16-byte segments of a tile
 constexpr int FT_SPT = (FT_SEGS + 255) / 256;            // segments per thread
 static_assert(FT_PITCH % 4 == 0 && FT_PITCH / 4 == FT_W / 16 + 2, "a tile row is the body plus one segment per side");
-struct FastStage16 {
-    uint4 v[FT_SPT];
-};
-
-// `inside` (workgroup-uniform): every segment of the tile lies inside the image, so nothing needs
-// clamping or zeroing.
-__device__ __forceinline__ bool fast_tile_inside(int H, int W, int x0, int y0)
-{
-    return x0 >= 16 && x0 + FT_W + 16 <= W && y0 >= 3 && y0 - 3 + FT_LH <= H;
-}
-
-__device__ __forceinline__ void fast_stage16_load(FastStage16& st, const uint8_t* __restrict__ img, int H,
-                                                  int W, int x0, int y0, bool inside)
-{
-    constexpr int SPR = FT_PITCH / 4;                        // segments per row
-    const int t = (int)threadIdx.x;
-    const int row0 = t / SPR, seg0 = t - SPR * row0;
-    if (inside) {
-        // segment t + 256 i is 256 i / SPR rows and 256 i % SPR segments further on (one wrap at most)
-        const uint32_t off0 = (uint32_t)(__mul24(y0 - 3 + row0, W) + x0 - 16 + 16 * seg0);
-#pragma unroll
-        for (int i = 0; i < FT_SPT; ++i) {
-            const int drow = (256 * i) / SPR, dseg = (256 * i) % SPR;
-            const bool wrap = seg0 + dseg >= SPR;
-            const uint32_t off = off0 + (uint32_t)(drow * W + 16 * dseg) + (wrap ? (uint32_t)(W - 16 * SPR) : 0u);
-            if (t + 256 * i < FT_SEGS) st.v[i] = *reinterpret_cast<const uint4*>(img + off);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < FT_SPT; ++i) {
-            const int idx = t + 256 * i;
-            const int row = idx / SPR, seg = idx - SPR * row;
-            int y = y0 - 3 + row, x = x0 - 16 + 16 * seg;
-            y = y < 0 ? 0 : (y < H ? y : H - 1);
-            x = x < 0 ? 0 : (x < W ? x : W - 16);
-            if (idx < FT_SEGS) st.v[i] = *reinterpret_cast<const uint4*>(img + (uint32_t)(__mul24(y, W) + x));
-        }
-    }
-}
-
-__device__ __forceinline__ void fast_stage16_store(const FastStage16& st, uint32_t* tile32, int H, int W,
-                                                   int x0, int y0, bool inside)
-{
-    constexpr int SPR = FT_PITCH / 4;
-    uint4* const lds4 = reinterpret_cast<uint4*>(tile32);
-    const int t = (int)threadIdx.x;
-    if (inside) {
-#pragma unroll
-        for (int i = 0; i < FT_SPT; ++i)
-            if (t + 256 * i < FT_SEGS) lds4[t + 256 * i] = st.v[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < FT_SPT; ++i) {
-            const int idx = t + 256 * i;
-            const int row = idx / SPR, seg = idx - SPR * row;
-            const int y = y0 - 3 + row, x = x0 - 16 + 16 * seg;
-            uint4 v = st.v[i];
-            if (!(y >= 0 && y < H && x >= 0 && x < W)) v = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < FT_SEGS) lds4[idx] = v;
-        }
-    }
-}
 
 // Staging for images whose rows are not whole aligned dwords: bytes assembled one by one.
 __device__ __forceinline__ void fast_stage_bytes(uint32_t* tile32, const uint8_t* __restrict__ img, int H,
