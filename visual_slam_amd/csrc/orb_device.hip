@@ -718,7 +718,8 @@ void launch_fast_mask(const FrameSet& fs, uint32_t* mask, int2* rowcnt, hipStrea
     int aligned = 1;
     if ((fs.W & 15) == 0 && ((uintptr_t)fs.gray & 15) == 0) aligned = 16;
     else if ((fs.W & 3) == 0 && ((uintptr_t)fs.gray & 3) == 0) aligned = 4;
-    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), 0, s, fs.gray, fs.H, fs.W, mask, MW, aligned, ntc, ntr,
+    static const unsigned pad = lds_pad_from_env("ORBAMD_PAD_LDS_FAST", (const void*)fast_mask_kernel);
+    hipLaunchKernelGGL(fast_mask_kernel, grid, dim3(256), pad, s, fs.gray, fs.H, fs.W, mask, MW, aligned, ntc, ntr,
                        reinterpret_cast<unsigned long long*>(rowcnt));
 }
 
