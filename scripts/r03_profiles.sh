@@ -5,10 +5,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r03_prof
 mkdir -p $OUT
 cd $R
-# traffic + kernel stats of the default bench (+ textured leg, + pipelined variant)
-bash scripts/profile_round.sh r03 r03 > $OUT/profile_round.log 2>&1 || { tail -20 $OUT/profile_round.log; exit 1; }
+# instruction mix first: the bench runs below replay it (and the traffic figures) from profiles/, so both files
+# have to be this build's before bench.py starts
+rm -f gpurun_out/pmc_r03/instruction_mix.json
 bash scripts/pmc_insts.sh r03 > $OUT/pmc_insts.log 2>&1 || { tail -20 $OUT/pmc_insts.log; exit 1; }
 cp gpurun_out/pmc_r03/instruction_mix.json profiles/r03_pmc_instruction_mix_1080p_1000frames.json
+# traffic + kernel stats of the default bench (+ textured leg, + pipelined variant)
+bash scripts/profile_round.sh r03 r03 > $OUT/profile_round.log 2>&1 || { tail -20 $OUT/profile_round.log; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 cd $R
 # other workloads: bench line + kernel stats each
